@@ -1,0 +1,132 @@
+/* libascent -- C ABI of the MI355X-native batched lunar-ascent NLP solver.
+ *
+ * Drop-in boundary.  The reference has no FFI of its own: its hot path is
+ * the single call  m.solve(disp=True)  at /root/reference/Launch_Optimiser.py:177, which ships the
+ * model declared at Launch_Optimiser.py:19-176 to GEKKO -> APMonitor -> IPOPT.  These entry points
+ * are what a GEKKO-compatible front end binds instead of that call (see INTEGRATION.md for the
+ * ctypes stub); lunar_module_ascent_trajectory_optimiser_amd/gekko_shim.py is such a front end.
+ *
+ * Conventions
+ *   - every entry point returns 0 on success or a negative ascent_status code (usage / HIP error,
+ *     text via ascent_strerror); per-problem solver outcomes go to status_out, never the return code
+ *   - plain pointers and sizes only; the caller owns every buffer; the library allocates only its
+ *     private per-device workspace
+ *   - all arrays are double precision, structure-of-arrays with the PROBLEM index fastest:
+ *       element (row r, problem p) of an array with `batch` problems lives at  a[r*batch + p]
+ *   - scaled units exactly as the reference's GEKKO variables (Launch_Optimiser.py:83-109):
+ *       lengths / Scalar (= r_peri), mass = burnt fraction of fuel_mass, angle = physical/3,
+ *       u = angular acceleration / ang_acc_max, tf = final time / T_scale
+ */
+#ifndef ASCENT_H
+#define ASCENT_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* One NLP's physical parameters, SI units.  Mirrors Launch_Optimiser.py:38-75,107-109. */
+typedef struct ascent_params {
+  double G;            /* :50  gravitational constant                                   */
+  double M;            /* :51  mass of the Moon, kg                                     */
+  double R0;           /* :52  lunar radius, m                                          */
+  double Ft;           /* :61  thrust, N                                                */
+  double M0;           /* :62  wet mass, kg                                             */
+  double mdot;         /* :63,65 propellant mass flow, kg/s (mflow = mdot/fuel_mass)    */
+  double fuel_mass;    /* :64  kg                                                       */
+  double mass_scalar;  /* :108 mass scale in (M0 - mass_scalar*mass); = fuel_mass in the
+                               current script, 2576 in the v1 script (PDF p26)          */
+  double ang_acc_max;  /* :66  angular-acceleration cap, rad/s^2                         */
+  double r_peri;       /* :70  target periapsis altitude, m (= Rfmin = Scalar, :73,107) */
+  double r_apo;        /* :71  target apoapsis altitude, m                              */
+  double T_scale;      /* :38  final_time = 470 s (time scale; tf in [tf_lb, tf_ub])    */
+  double angle_ub;     /* :94  upper bound of angle (= physical/3), pi/3                */
+  double tf_lb;        /* :39                                                            */
+  double tf_ub;        /* :39                                                            */
+  double dcost;        /* :99  MV movement penalty (accepted)             */
+} ascent_params;
+
+typedef struct ascent_opts {
+  int32_t n_nodes;     /* :20  nt, number of grid points (tau_k = k/(nt-1), :21)         */
+  int32_t scheme;      /* 0 = NODES=2 two-point collocation = backward Euler (:25)      */
+  int32_t max_iter;    /* :28  interior-point iteration cap                              */
+  int32_t warm_start;  /* 0 = built-in cold-start guess, 1 = primal part of `guess`,
+                          2 = full primal-dual `guess` (multipliers kept)                */
+  double tol;          /* KKT error tolerance (the reference's OTOL/RTOL, :31-32)        */
+  double mu_init;      /* initial barrier parameter (<=0: 0.1 cold, 1e-4 warm)           */
+} ascent_opts;
+
+enum ascent_status {           /* function return codes */
+  ASCENT_OK = 0,
+  ASCENT_E_ARG = -1,           /* null pointer / bad size / unsupported option           */
+  ASCENT_E_HIP = -2,           /* a HIP runtime call failed (see ascent_strerror)        */
+  ASCENT_E_NODEVICE = -3,      /* no such device                                         */
+  ASCENT_E_NOMEM = -4          /* workspace allocation failed                            */
+};
+
+enum ascent_problem_status {   /* values written to status_out[] */
+  ASCENT_CONVERGED = 0,
+  ASCENT_MAX_ITER = 1,
+  ASCENT_LINESEARCH_FAILED = 2,
+  ASCENT_REGULARISATION_FAILED = 3   /* numerical breakdown: inertia could not be corrected */
+};
+
+/* Row counts of the SoA arrays, K = n_nodes-1 (node 0 is fixed by the initial conditions,
+ * Launch_Optimiser.py:145-151):
+ *   iterate / step / guess "blob":  21*K + 10 rows
+ *       rows [0,7K)     z_k  : node k=1..K, fields x y xdot ydot angle angledot mass  (row 7(k-1)+f)
+ *       rows [7K,8K)    u_k  : angledoubledot
+ *       rows [8K,15K)   lambda_k : multipliers of the 7 collocation defects of step k
+ *       rows [15K,21K)  bound multipliers zL_angle zU_angle zL_mass zU_mass zL_u zU_u per node
+ *       rows 21K..21K+9 tf, zL_tf, zU_tf, s1, s2, z_s1, z_s2, nu3, nu1, nu2
+ *                       (s_i: slacks of the two terminal inequalities :161,:169; nu: multipliers of
+ *                        the terminal r.v = 0 (:173) and of the two slack equations)
+ *   traj_out: 10*n_nodes rows, row f*n_nodes + k, fields in the order of the reference's .value
+ *       lists: x y xdot ydot xdoubledot ydoubledot angle angledot angledoubledot mass  (:187-202)
+ */
+#define ASCENT_BLOB_ROWS(n_nodes) (21 * ((n_nodes) - 1) + 10)
+#define ASCENT_TRAJ_FIELDS 10
+
+int ascent_version(void);
+int ascent_device_count(void);
+const char *ascent_strerror(int code);
+
+/* Solve `batch` independent ascent NLPs (replaces m.solve, Launch_Optimiser.py:177).
+ * p: AoS [batch] parameter structs (host or device per ptr_is_device, like every other pointer).
+ * guess_or_null: blob [21K+10][batch] when o->warm_start != 0.
+ * traj_out [10*n_nodes][batch], tf_out/status_out/iters_out [batch]; sol_blob_out_or_null
+ * [21K+10][batch] receives the full primal-dual solution (usable as a warm start).
+ * stream: hipStream_t or NULL.  The call is synchronous with respect to the host unless
+ * ptr_is_device != 0 and a stream is given, in which case it only enqueues work. */
+int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts *o,
+                       const double *guess_or_null, double *traj_out, double *tf_out,
+                       int32_t *status_out, int32_t *iters_out, double *sol_blob_out_or_null,
+                       int device_id, void *hip_stream_or_null, int ptr_is_device);
+
+/* Per-node pieces of the path, exposed for parity testing (Launch_Optimiser.py:114-136):
+ * iterate: blob [21K+10][batch] (z, u, lambda, tf are read).
+ * defects [7K][batch]: z_k - z_{k-1} - h*T*tf*f(z_k,u_k), row 7(k-1)+f.
+ * jac_blocks [8K][batch]: d(xdoubledot)/d(x,y,angle,mass), d(ydoubledot)/d(x,y,angle,mass).
+ * hess_blocks [10K][batch]: upper triangle (xx xy xa xm yy ya ym aa am mm) of the Hessian of
+ *   -h*T*tf*(lambda_xdot*xdoubledot + lambda_ydot*ydoubledot), the node's Lagrangian block.
+ * Host pointers. */
+int ascent_eval_nodes(const ascent_params *p, int64_t batch, const ascent_opts *o,
+                      const double *iterate, double *defects, double *jac_blocks,
+                      double *hess_blocks, int device_id);
+
+/* One Newton step of the barrier problem: factorises and solves the bordered block-tridiagonal
+ * KKT system at `iterate` with barrier parameter mu[p] and primal regularisation delta_w[p].
+ * step [21K+10][batch]; inertia_out[p] = 0 if the KKT matrix had the correct inertia, 1 if not
+ * (step then undefined).  Host pointers. */
+int ascent_kkt_step(const ascent_params *p, int64_t batch, const ascent_opts *o,
+                    const double *iterate, const double *mu, const double *delta_w, double *step,
+                    int32_t *inertia_out, int device_id);
+
+/* Device time (ms) of the solve kernel of the most recent ascent_solve_batch on this device,
+ * measured with HIP events on the launch stream; < 0 if none. */
+double ascent_last_kernel_ms(int device_id);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ASCENT_H */

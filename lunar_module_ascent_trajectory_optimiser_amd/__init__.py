@@ -1,0 +1,11 @@
+"""MI355X-native batched lunar-ascent trajectory optimiser.
+
+The package holds only the hot path of Ben-Bussch/Lunar_Module_Ascent_Trajectory_Optimiser
+(the NLP solve behind Launch_Optimiser.py:177): csrc/ (HIP kernels + C ABI, include/ascent.h)
+and the host-side mirror of the reference's problem-definition surface.
+"""
+from .params import AscentParams, sweep_isp_drymass, sweep_config4, PARAM_FIELDS  # noqa: F401
+from .solver import solve_batch, eval_nodes, kkt_step, BatchResult, TRAJ_FIELDS, blob_rows  # noqa: F401
+
+__all__ = ["AscentParams", "sweep_isp_drymass", "sweep_config4", "solve_batch", "eval_nodes", "kkt_step",
+           "BatchResult", "TRAJ_FIELDS", "PARAM_FIELDS", "blob_rows"]

@@ -1,0 +1,37 @@
+"""Builds csrc/libascent.so for gfx950 with hipcc (in-tree, no JIT cache)."""
+from __future__ import annotations
+
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+ROOT = os.path.dirname(HERE)
+LIB = os.path.join(CSRC, "libascent.so")
+SOURCES = ["ascent_solver.hip"]
+HEADERS = ["ascent_device.hpp", os.path.join(ROOT, "include", "ascent.h")]
+
+
+def needs_build() -> bool:
+    if not os.path.exists(LIB):
+        return True
+    t = os.path.getmtime(LIB)
+    deps = [os.path.join(CSRC, s) for s in SOURCES] + [h if os.path.isabs(h) else os.path.join(CSRC, h) for h in HEADERS]
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    if not force and not needs_build():
+        return LIB
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared",
+           "-I", os.path.join(ROOT, "include"), "-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    if verbose:
+        print(" ".join(cmd), file=sys.stderr)
+    subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    print(build(force="--force" in sys.argv, verbose=True))

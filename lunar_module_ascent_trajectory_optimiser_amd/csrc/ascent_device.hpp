@@ -1,0 +1,272 @@
+// Device-side building blocks of the batched ascent NLP solver (gfx950, FP64 VALU).
+//
+// Mapping: one lane = one NLP.  Every per-problem array is structure-of-arrays with the problem
+// index fastest, so the 64 lanes of a wavefront touch 64 consecutive doubles (one 512-B
+// transaction) for every row they read or write; there is no cross-lane traffic at all.
+// The time axis (the 199 collocation steps of /root/reference/Launch_Optimiser.py:20-21) is swept
+// serially per lane: backward (evaluate + Riccati factorise), forward (primal step), backward
+// (adjoint / multipliers).  The free final time tf (Launch_Optimiser.py:39-40) couples every
+// step, and the terminal r.v = 0 constraint (:173) is a second global unknown: both are carried
+// as border columns (two extra right-hand sides) of the block-tridiagonal system and closed by a
+// 2x2 Schur complement whose entries are accumulated during the backward sweep.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <math.h>
+#include "ascent.h"
+
+namespace ascent {
+
+constexpr int IX = 0, IY = 1, IVX = 2, IVY = 3, IA = 4, IW = 5, IM = 6;
+// scalar rows at the end of a blob
+constexpr int S_TH = 0, S_ZLT = 1, S_ZUT = 2, S_S1 = 3, S_S2 = 4, S_ZS1 = 5, S_ZS2 = 6, S_NU3 = 7,
+              S_NU1 = 8, S_NU2 = 9, NSC = 10;
+
+#define ASC_DEV __device__ __forceinline__
+#define ASC_UNROLL _Pragma("unroll")
+
+// index into a packed upper-triangular symmetric 7x7 (28 entries)
+__host__ __device__ constexpr int sid(int i, int j) {
+  return i <= j ? (i * 7 - (i * (i - 1)) / 2 + (j - i)) : (j * 7 - (j * (j - 1)) / 2 + (i - j));
+}
+
+struct Der {  // constants derived from ascent_params (Launch_Optimiser.py:65,72-75,107-109)
+  double rho0, rhof, vp2, gam, thr, alpha, mrate, ms, M0, T, aub, tlb, tub;
+};
+
+ASC_DEV Der derive(const ascent_params &p) {
+  Der d;
+  const double S = p.r_peri, GM = p.G * p.M;
+  const double ravg = 0.5 * (p.r_peri + p.r_apo);
+  const double vper2 = GM / (p.R0 + ravg);
+  d.rho0 = p.R0 / S;
+  d.rhof = (p.R0 + S) / S;
+  d.vp2 = vper2 / (S * S);
+  d.gam = GM / (S * S * S);
+  d.thr = p.Ft / S;
+  d.alpha = p.ang_acc_max / 3.0;
+  d.mrate = p.mdot / p.fuel_mass;
+  d.ms = p.mass_scalar;
+  d.M0 = p.M0;
+  d.T = p.T_scale;
+  d.aub = p.angle_ub;
+  d.tlb = p.tf_lb;
+  d.tub = p.tf_ub;
+  return d;
+}
+
+// Scaled accelerations xdoubledot / ydoubledot (Launch_Optimiser.py:133-136 / 127-130) in polar
+// form: a = th(m) * d(phi + 3*angle) - gam * e(phi) / rho^2, e = radial unit vector.
+// LEVEL 0: values; 1: + gradients g[0..3] = d ax/d(x,y,angle,mass), g[4..7] = d ay/d(..);
+// 2: + H[10] = upper triangle of the Hessian of px*ax + py*ay.
+template <int LEVEL>
+ASC_DEV void accel(const Der &d, double x, double y, double a, double m, double px, double py,
+                   double &ax, double &ay, double *g, double *H) {
+  const double xi = x, et = y + d.rho0;
+  const double r2 = xi * xi + et * et;
+  const double ir = rsqrt(r2);
+  const double ex = xi * ir, ey = et * ir;
+  double s, c;
+  sincos(3.0 * a, &s, &c);
+  const double dx = ex * c - ey * s, dy = ey * c + ex * s;
+  const double imp = 1.0 / (d.M0 - d.ms * m);
+  const double th = d.thr * imp;
+  const double g3 = d.gam * ir * ir * ir;
+  ax = th * dx - g3 * xi;
+  ay = th * dy - g3 * et;
+  if constexpr (LEVEL >= 1) {
+    const double th1 = th * d.ms * imp;
+    const double fx = -ey * ir, fy = ex * ir;
+    const double qx = -dy, qy = dx;
+    const double g3e = 3.0 * g3 * ex * ey;
+    g[0] = th * qx * fx - g3 * (1.0 - 3.0 * ex * ex);
+    g[1] = th * qx * fy + g3e;
+    g[2] = 3.0 * th * qx;
+    g[3] = th1 * dx;
+    g[4] = th * qy * fx + g3e;
+    g[5] = th * qy * fy - g3 * (1.0 - 3.0 * ey * ey);
+    g[6] = 3.0 * th * qy;
+    g[7] = th1 * dy;
+    if constexpr (LEVEL >= 2) {
+      const double th2 = 2.0 * th1 * d.ms * imp;
+      const double pd = px * dx + py * dy, pp = px * qx + py * qy, pe = px * ex + py * ey;
+      const double ir2 = ir * ir;
+      const double fxx = 2.0 * ex * ey * ir2, fxy = (ey * ey - ex * ex) * ir2;
+      const double g4 = 3.0 * g3 * ir;
+      const double tpd = th * pd, tpp = th * pp;
+      H[0] = -tpd * fx * fx + tpp * fxx + g4 * (2.0 * px * ex + pe - 5.0 * pe * ex * ex);
+      H[1] = -tpd * fx * fy + tpp * fxy + g4 * (px * ey + py * ex - 5.0 * pe * ex * ey);
+      H[2] = -3.0 * tpd * fx;
+      H[3] = th1 * pp * fx;
+      H[4] = -tpd * fy * fy - tpp * fxx + g4 * (2.0 * py * ey + pe - 5.0 * pe * ey * ey);
+      H[5] = -3.0 * tpd * fy;
+      H[6] = th1 * pp * fy;
+      H[7] = -9.0 * tpd;
+      H[8] = 3.0 * th1 * pp;
+      H[9] = th2 * pd;
+    }
+  }
+}
+
+// 2x2 inverse E of (I - dt^2 * d(ax,ay)/d(x,y)): the implicit (backward-Euler) position/velocity block
+ASC_DEV void implicit_block(const double *G, double dt, double *E) {
+  const double d2 = dt * dt;
+  const double m11 = 1.0 - d2 * G[0], m12 = -d2 * G[1], m21 = -d2 * G[4], m22 = 1.0 - d2 * G[5];
+  const double idet = 1.0 / (m11 * m22 - m12 * m21);
+  E[0] = m22 * idet;
+  E[1] = -m12 * idet;
+  E[2] = -m21 * idet;
+  E[3] = m11 * idet;
+}
+
+// v = A^-1 r,  A = I - dt * df/dz  (the step Jacobian of the backward-Euler defect w.r.t. z_k)
+ASC_DEV void solveA(const double *G, const double *E, double dt, const double *r, double *v) {
+  const double vw = r[IW], vm = r[IM], va = r[IA] + dt * vw;
+  const double t1 = r[IVX] + dt * (G[0] * r[IX] + G[1] * r[IY] + G[2] * va + G[3] * vm);
+  const double t2 = r[IVY] + dt * (G[4] * r[IX] + G[5] * r[IY] + G[6] * va + G[7] * vm);
+  const double vvx = E[0] * t1 + E[1] * t2, vvy = E[2] * t1 + E[3] * t2;
+  v[IX] = r[IX] + dt * vvx;
+  v[IY] = r[IY] + dt * vvy;
+  v[IVX] = vvx;
+  v[IVY] = vvy;
+  v[IA] = va;
+  v[IW] = vw;
+  v[IM] = vm;
+}
+
+// v = A^-T r
+ASC_DEV void solveAT(const double *G, const double *E, double dt, const double *r, double *v) {
+  const double t1 = r[IVX] + dt * r[IX], t2 = r[IVY] + dt * r[IY];
+  const double vvx = E[0] * t1 + E[2] * t2, vvy = E[1] * t1 + E[3] * t2;
+  const double va = r[IA] + dt * (G[2] * vvx + G[6] * vvy);
+  v[IX] = r[IX] + dt * (G[0] * vvx + G[4] * vvy);
+  v[IY] = r[IY] + dt * (G[1] * vvx + G[5] * vvy);
+  v[IVX] = vvx;
+  v[IVY] = vvy;
+  v[IA] = va;
+  v[IM] = r[IM] + dt * (G[3] * vvx + G[7] * vvy);
+  v[IW] = r[IW] + dt * va;
+}
+
+// N <- T N T',  T = I + c e_I e_J'   (packed symmetric N)
+template <int I, int J>
+ASC_DEV void cong_add(double *N, double c) {
+  const double nij = N[sid(I, J)], njj = N[sid(J, J)];
+  ASC_UNROLL
+  for (int l = 0; l < 7; l++)
+    if (l != I) N[sid(I, l)] += c * N[sid(J, l)];
+  N[sid(I, I)] += c * (2.0 * nij + c * njj);
+}
+
+// N <- A^-T N A^-1 as four in-place congruences (A^-T = T4 T3 T2 T1, see solveAT):
+//   T1: rows xdot,ydot += dt * rows x,y;  T2: 2x2 block E' on (xdot,ydot);
+//   T3: rows x,y,angle,mass += dt * G' (rows xdot,ydot);  T4: row angledot += dt * row angle.
+ASC_DEV void congruence(double *N, const double *G, const double *E, double dt) {
+  cong_add<IVX, IX>(N, dt);
+  cong_add<IVY, IY>(N, dt);
+  {  // T2
+    ASC_UNROLL
+    for (int l = 0; l < 7; l++) {
+      if (l == IVX || l == IVY) continue;
+      const double a = N[sid(IVX, l)], b = N[sid(IVY, l)];
+      N[sid(IVX, l)] = E[0] * a + E[2] * b;
+      N[sid(IVY, l)] = E[1] * a + E[3] * b;
+    }
+    const double b11 = N[sid(IVX, IVX)], b12 = N[sid(IVX, IVY)], b22 = N[sid(IVY, IVY)];
+    const double t11 = E[0] * b11 + E[2] * b12, t12 = E[0] * b12 + E[2] * b22;
+    const double t21 = E[1] * b11 + E[3] * b12, t22 = E[1] * b12 + E[3] * b22;
+    N[sid(IVX, IVX)] = t11 * E[0] + t12 * E[2];
+    N[sid(IVX, IVY)] = t11 * E[1] + t12 * E[3];
+    N[sid(IVY, IVY)] = t21 * E[1] + t22 * E[3];
+  }
+  cong_add<IX, IVX>(N, dt * G[0]);
+  cong_add<IX, IVY>(N, dt * G[4]);
+  cong_add<IY, IVX>(N, dt * G[1]);
+  cong_add<IY, IVY>(N, dt * G[5]);
+  cong_add<IA, IVX>(N, dt * G[2]);
+  cong_add<IA, IVY>(N, dt * G[6]);
+  cong_add<IM, IVX>(N, dt * G[3]);
+  cong_add<IM, IVY>(N, dt * G[7]);
+  cong_add<IW, IA>(N, dt);
+}
+
+// y = N v for packed symmetric N
+ASC_DEV void symv(const double *N, const double *v, double *y) {
+  ASC_UNROLL
+  for (int i = 0; i < 7; i++) {
+    double a = 0.0;
+    ASC_UNROLL
+    for (int l = 0; l < 7; l++) a += N[sid(i, l)] * v[l];
+    y[i] = a;
+  }
+}
+
+// F_z' lambda : (d f/d z)' applied to the defect multipliers of a node
+ASC_DEV void fzt_lambda(const double *G, const double *l, double *fl) {
+  fl[IX] = G[0] * l[IVX] + G[4] * l[IVY];
+  fl[IY] = G[1] * l[IVX] + G[5] * l[IVY];
+  fl[IVX] = l[IX];
+  fl[IVY] = l[IY];
+  fl[IA] = G[2] * l[IVX] + G[6] * l[IVY];
+  fl[IW] = l[IA];
+  fl[IM] = G[3] * l[IVX] + G[7] * l[IVY];
+}
+
+// right-hand side f(z,u) of the scaled ODEs without the tf*T factor (Launch_Optimiser.py:114-123)
+ASC_DEV void rhs_f(const Der &d, const double *z, double u, double ax, double ay, double *F) {
+  F[IX] = z[IVX];
+  F[IY] = z[IVY];
+  F[IVX] = ax;
+  F[IVY] = ay;
+  F[IA] = z[IW];
+  F[IW] = d.alpha * u;
+  F[IM] = d.mrate;
+}
+
+// Terminal constraints at the last node (Launch_Optimiser.py:158-173, divided through by Scalar^2
+// where the reference multiplies positions and velocities by Scalar):
+//   e3 = (y+rho0)*ydot + x*xdot = 0 ;  g1 = |(x, y+rho0)| - rhof - s1 = 0 ;  g2 = xdot^2+ydot^2 - vp2 - s2 = 0
+struct Terminal {
+  double e3, g1, g2;        // constraint values (g_i before subtracting the slack)
+  double e3g[4];            // d e3 / d(x,y,xdot,ydot)
+  double g1g[2];            // d g1 / d(x,y)
+  double g2g[2];            // d g2 / d(xdot,ydot)
+  double hxx, hxy, hyy;     // second derivatives of g1
+};
+
+ASC_DEV Terminal terminal_eval(const Der &d, const double *z) {
+  Terminal t;
+  const double et = z[IY] + d.rho0;
+  const double r2 = z[IX] * z[IX] + et * et;
+  const double ir = rsqrt(r2), rho = r2 * ir;
+  const double ex = z[IX] * ir, ey = et * ir;
+  t.e3 = et * z[IVY] + z[IX] * z[IVX];
+  t.g1 = rho - d.rhof;
+  t.g2 = z[IVX] * z[IVX] + z[IVY] * z[IVY] - d.vp2;
+  t.e3g[0] = z[IVX];
+  t.e3g[1] = z[IVY];
+  t.e3g[2] = z[IX];
+  t.e3g[3] = et;
+  t.g1g[0] = ex;
+  t.g1g[1] = ey;
+  t.g2g[0] = 2.0 * z[IVX];
+  t.g2g[1] = 2.0 * z[IVY];
+  t.hxx = ey * ey * ir;
+  t.hxy = -ex * ey * ir;
+  t.hyy = ex * ex * ir;
+  return t;
+}
+
+// adds the terminal Lagrangian Hessian and the slack-eliminated barrier terms to the last node's Q
+ASC_DEV void terminal_hessian(double *Q, const Terminal &t, double nu3, double nu1, double nu2,
+                              double sig1, double sig2) {
+  Q[sid(IX, IX)] += nu1 * t.hxx + sig1 * t.g1g[0] * t.g1g[0];
+  Q[sid(IX, IY)] += nu1 * t.hxy + sig1 * t.g1g[0] * t.g1g[1];
+  Q[sid(IY, IY)] += nu1 * t.hyy + sig1 * t.g1g[1] * t.g1g[1];
+  Q[sid(IVX, IVX)] += 2.0 * nu2 + sig2 * t.g2g[0] * t.g2g[0];
+  Q[sid(IVX, IVY)] += sig2 * t.g2g[0] * t.g2g[1];
+  Q[sid(IVY, IVY)] += 2.0 * nu2 + sig2 * t.g2g[1] * t.g2g[1];
+  Q[sid(IX, IVX)] += nu3;
+  Q[sid(IY, IVY)] += nu3;
+}
+
+}  // namespace ascent

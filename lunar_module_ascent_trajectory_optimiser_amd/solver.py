@@ -1,0 +1,130 @@
+"""Host-side API over libascent (include/ascent.h): the replacement of the reference's
+`m.solve()` call (/root/reference/Launch_Optimiser.py:177) for batches of ascent NLPs."""
+from __future__ import annotations
+
+import ctypes as C
+import dataclasses
+
+import numpy as np
+
+from . import _lib
+from .params import AscentParams, pack
+
+TRAJ_FIELDS = ("x", "y", "xdot", "ydot", "xdoubledot", "ydoubledot", "angle", "angledot",
+               "angledoubledot", "mass")
+STATUS_NAMES = {0: "converged", 1: "max_iter", 2: "linesearch_failed", 3: "regularisation_failed"}
+
+
+def blob_rows(nt: int) -> int:
+    return 21 * (nt - 1) + 10
+
+
+def _opts(nt, max_iter, tol, warm_start, mu_init):
+    return _lib.AscentOptsC(n_nodes=nt, scheme=0, max_iter=max_iter, warm_start=warm_start, tol=tol,
+                            mu_init=mu_init)
+
+
+def _ptr(a):
+    return None if a is None else a.ctypes.data_as(C.c_void_p)
+
+
+@dataclasses.dataclass
+class BatchResult:
+    """Solutions of a batch. Arrays keep the library's layout: problem index last."""
+    params: np.ndarray          # (batch, 16)
+    nt: int
+    traj: np.ndarray            # (10, nt, batch) scaled, fields TRAJ_FIELDS (reference .value lists)
+    tf: np.ndarray              # (batch,)  scaled final time (tf.value[0])
+    status: np.ndarray          # (batch,) int32, see STATUS_NAMES
+    iters: np.ndarray           # (batch,) int32
+    blob: np.ndarray | None     # (21K+10, batch) primal-dual solution (warm-start material)
+    kernel_ms: float            # device time of the solve kernel
+
+    @property
+    def converged(self) -> np.ndarray:
+        return self.status == 0
+
+    def field(self, name: str) -> np.ndarray:
+        """(nt, batch) array of one of TRAJ_FIELDS, in the reference's scaled units."""
+        return self.traj[TRAJ_FIELDS.index(name)]
+
+    def final_time(self) -> np.ndarray:
+        """seconds: tf.value[0]*final_time (Launch_Optimiser.py:194)."""
+        return self.tf * self.params[:, 11]
+
+    def outputs(self, i: int = 0) -> dict:
+        """The quantities the reference prints/plots for problem i (Launch_Optimiser.py:178-202):
+        physical t, x_pos (sign flipped as :200), y_pos (:201), theta in degrees (:202), mass, and
+        the polar (r, theta_polar) of north_star."""
+        P = self.params[i]
+        S, R0, T, M0, ms = P[9], P[2], P[11], P[4], P[7]
+        tr = self.traj[:, :, i]
+        x, y = tr[0], tr[1]
+        X, Y = x * S, y * S + R0
+        return dict(
+            t=np.linspace(0.0, 1.0, self.nt) * self.tf[i] * T,
+            x_pos=-X, y_pos=Y, theta_deg=3.0 * tr[6] * 180.0 / np.pi,
+            r=np.hypot(X, Y), theta_polar=np.arctan2(-X, Y), control_angle=3.0 * tr[6],
+            mass_kg=M0 - ms * tr[9],
+            final_y=y[-1] * S, final_x=x[-1] * S, final_ydot=tr[3, -1] * S, final_xdot=tr[2, -1] * S,
+            final_ydoubledot=tr[5, -1] * S, final_xdoubledot=tr[4, -1] * S,
+            final_time=self.tf[i] * T, tf=self.tf[i],
+        )
+
+
+def solve_batch(params, nt: int = 200, tol: float = 1e-9, max_iter: int = 300, guess: np.ndarray | None = None,
+                warm_start: int | None = None, mu_init: float = 0.0, device: int = 0, want_traj: bool = True,
+                want_blob: bool = False) -> BatchResult:
+    """Solve a batch of ascent NLPs on one GPU.  params: AscentParams | list | (batch,16) array.
+    guess: (21K+10, batch) blob, with warm_start 1 (primal only) or 2 (primal-dual)."""
+    L = _lib.load()
+    P = pack(params)
+    B = P.shape[0]
+    rows = blob_rows(nt)
+    if guess is not None:
+        guess = np.ascontiguousarray(guess, dtype=np.float64)
+        if guess.shape != (rows, B):
+            raise ValueError(f"guess must have shape {(rows, B)}")
+        if warm_start is None:
+            warm_start = 1
+    warm_start = warm_start or 0
+    traj = np.empty((10, nt, B)) if want_traj else None
+    blob = np.empty((rows, B)) if want_blob else None
+    tf = np.empty(B)
+    status = np.empty(B, dtype=np.int32)
+    iters = np.empty(B, dtype=np.int32)
+    o = _opts(nt, max_iter, tol, warm_start, mu_init)
+    _lib.check(L.ascent_solve_batch(_ptr(P), B, C.byref(o), _ptr(guess), _ptr(traj), _ptr(tf), _ptr(status),
+                                    _ptr(iters), _ptr(blob), device, None, 0))
+    return BatchResult(P, nt, traj, tf, status, iters, blob, L.ascent_last_kernel_ms(device))
+
+
+def eval_nodes(params, iterate: np.ndarray, nt: int = 200, device: int = 0):
+    """Per-step defects (7K,batch), Jacobian blocks (8K,batch), Hessian blocks (10K,batch)."""
+    L = _lib.load()
+    P = pack(params)
+    B, K = P.shape[0], nt - 1
+    it = np.ascontiguousarray(iterate, dtype=np.float64)
+    if it.shape != (blob_rows(nt), B):
+        raise ValueError("iterate has the wrong shape")
+    d, j, h = np.empty((7 * K, B)), np.empty((8 * K, B)), np.empty((10 * K, B))
+    o = _opts(nt, 0, 1.0, 0, 0.0)
+    _lib.check(L.ascent_eval_nodes(_ptr(P), B, C.byref(o), _ptr(it), _ptr(d), _ptr(j), _ptr(h), device))
+    return d, j, h
+
+
+def kkt_step(params, iterate: np.ndarray, mu, delta_w, nt: int = 200, device: int = 0):
+    """One Newton step of the barrier problem at `iterate` -> (step blob, inertia flags)."""
+    L = _lib.load()
+    P = pack(params)
+    B = P.shape[0]
+    it = np.ascontiguousarray(iterate, dtype=np.float64)
+    if it.shape != (blob_rows(nt), B):
+        raise ValueError("iterate has the wrong shape")
+    mu = np.ascontiguousarray(np.broadcast_to(np.asarray(mu, dtype=np.float64), (B,)))
+    dw = np.ascontiguousarray(np.broadcast_to(np.asarray(delta_w, dtype=np.float64), (B,)))
+    step = np.empty_like(it)
+    inertia = np.empty(B, dtype=np.int32)
+    o = _opts(nt, 0, 1.0, 0, 0.0)
+    _lib.check(L.ascent_kkt_step(_ptr(P), B, C.byref(o), _ptr(it), _ptr(mu), _ptr(dw), _ptr(step), _ptr(inertia), device))
+    return step, inertia
