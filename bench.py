@@ -1,0 +1,198 @@
+#!/usr/bin/env python3
+"""Headline benchmark: converged N=200 ascent NLPs per second (BASELINE.json metric).
+
+A "step" = one pass of the hot path over one batch per GPU: `batch_per_gpu` independent ascent NLPs
+solved from the built-in cold start to KKT error <= tol, parameters already resident in HBM, results
+left in HBM, then the single result gather (tf, status, iters) to rank 0.
+Workload at N=1: BASELINE.json configs[2] -- the 4096-NLP Isp x dry-mass sweep.
+With N ranks (weak scaling) rank r solves the same 64x64 grid for its own target apoapsis, i.e. a
+slice of the config-4 grid; --batch-per-gpu 32768 with --gpus 8 is config 4 itself.
+
+Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic HBM bytes of the solve kernel
+(B_alg = B_io + I*B_iter per NLP, I = iterations actually taken) / its HIP-event time;
+`cpu_baseline` = the plain-C oracle on the host cores for a bounded sample of the same workload.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NT = 200
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_PEAK_TFLOPS = 78.6        # MI355X FP64 vector = matrix
+APO_KM = np.linspace(70.0, 105.0, 8)
+
+
+def algorithmic_bytes(iters: np.ndarray, nt: int) -> float:
+    """B_io = params + full trajectory + (tf,status,iters); B_iter = 21 doubles read +
+    21 written per node per interior-point iteration."""
+    b_io = 16 * 8 + 10 * nt * 8 + 16
+    b_iter = 2 * 21 * 8 * nt
+    return float(len(iters) * b_io + iters.sum() * b_iter)
+
+
+def algorithmic_flops(iters: np.ndarray, nt: int) -> float:
+    """SURVEY.md 8d work-optimal count: ~4e3 flop per node per iteration."""
+    return float(iters.sum() * 4e3 * nt)
+
+
+def rank_params(batch: int, rank: int, world: int) -> np.ndarray:
+    import lunar_module_ascent_trajectory_optimiser_amd as A
+    if batch == 32768 and world == 8:               # exact config-4 shard
+        full = A.sweep_config4()
+        return np.ascontiguousarray(full[rank * batch:(rank + 1) * batch])
+    n = int(round(batch ** 0.5))
+    if n * n != batch:
+        raise SystemExit("--batch-per-gpu must be a perfect square (Isp x dry-mass grid) ")
+    base = A.AscentParams() if rank == 0 else A.AscentParams(r_apo=float(APO_KM[rank % 8]) * 1e3)
+    return A.sweep_isp_drymass(n, n, base=base)
+
+
+def cpu_baseline(params: np.ndarray, nt: int, tol: float, sample: int):
+    """Times the plain-C oracle (oracle/ascent_oracle.c, kind "port") on all host cores."""
+    from concurrent.futures import ThreadPoolExecutor
+    from oracle import c_oracle
+    c_oracle.build()
+    cores = len(os.sched_getaffinity(0))
+    idx = np.linspace(0, len(params) - 1, sample).astype(int)
+    S = np.ascontiguousarray(params[idx])
+    chunks = np.array_split(np.arange(sample), cores * 4)
+    c_oracle.solve_batch(S[:1], nt, 300, tol)      # load + warm
+    t0 = time.perf_counter()
+    with ThreadPoolExecutor(cores) as ex:           # ctypes releases the GIL during the C call
+        res = list(ex.map(lambda ch: c_oracle.solve_batch(S[ch], nt, 300, tol), [c for c in chunks if len(c)]))
+    dt = time.perf_counter() - t0
+    ok = sum(int((r["status"] == 0).sum()) for r in res)
+    return dict(value=ok / dt, unit="NLPs/s", cores=cores, kind="port",
+                sample=f"{sample} of the {len(params)} NLPs (every {len(params)//sample}th), same tol and cold start, "
+                       f"{dt:.2f} s wall on {cores} threads; CPU restatement, not GEKKO/IPOPT"), idx, res
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch-per-gpu", type=int, default=4096)
+    ap.add_argument("--tol", type=float, default=1e-9)
+    ap.add_argument("--cpu-sample", type=int, default=2048)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import lunar_module_ascent_trajectory_optimiser_amd as A
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    B = args.batch_per_gpu
+    P = rank_params(B, rank, world)
+    P_t = torch.from_numpy(P).to(dev)                      # inputs resident in HBM before timing
+    out = {}
+    gathered = [torch.empty((B, 3), dtype=torch.float64, device=dev) for _ in range(world)] if (dist and rank == 0) else None
+
+    def step():
+        A.solve_batch_torch(P_t, NT, tol=args.tol, want_traj=True, out=out)
+        if dist:                                           # the job's only collective: result gather
+            pack = torch.stack([out["tf"], out["status"].double(), out["iters"].double()], dim=1)
+            dist.gather(pack, gathered, dst=0)
+
+    def barrier():
+        if dist:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    kernel_ms = []
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        kernel_ms.append(A.last_kernel_ms(local))          # HIP events on the launch stream (waits for the kernel)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    iters = out["iters"].cpu().numpy()
+    status = out["status"].cpu().numpy()
+    conv_local = int((status == 0).sum())
+    conv_total = conv_local
+    if dist:
+        t = torch.tensor([conv_local], dtype=torch.float64, device=dev)
+        dist.all_reduce(t)
+        conv_total = int(t.item())
+    if rank == 0:
+        k_ms = float(np.mean(kernel_ms))
+        b_alg = algorithmic_bytes(iters, NT)
+        f_alg = algorithmic_flops(iters, NT)
+        achieved = b_alg / (k_ms * 1e-3) / 1e9
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.exists(tpath):
+            tj = json.load(open(tpath))
+            traffic = tj.get(f"batch{B}", {}).get("hbm_bytes_per_launch")
+        line = {
+            "metric": "solved ascent NLPs/sec (N=200 collocation nodes)",
+            "value": conv_total * args.steps / elapsed,
+            "unit": "NLPs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {
+                "workload": ("BASELINE.json configs[2]: 4096-NLP Isp x dry-mass sweep (64x64, Isp 300-320 s, dry mass 2345-2545 kg)"
+                             if B == 4096 else f"{B}-NLP sweep per GPU") + ", N=200 nodes, backward Euler (reference NODES=2)",
+                "batch_per_gpu": B, "global_batch": B * world, "n_nodes": NT, "tol": args.tol,
+                "start": "cold (built-in straight-line guess, mu0=0.1)", "parallelism": f"problem-sharded x{world}, gather only",
+                "iterations_min_mean_max": [int(iters.min()), float(iters.mean()), int(iters.max())],
+                "converged": conv_total, "of": B * world,
+            },
+            "roofline": {
+                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                "kernel": "k_solve", "kernel_ms": k_ms, "algorithmic_bytes_per_launch": b_alg,
+                "fp64_achieved_tflops": f_alg / (k_ms * 1e-3) / 1e12,
+                "fp64_frac": f_alg / (k_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                "note": "latency/FP64-issue bound, not HBM-bound: see DESIGN.md (both fractions reported as SURVEY 8d asks)",
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            cb, idx, res = cpu_baseline(P, NT, args.tol, min(args.cpu_sample, B))
+            tf_cpu = np.concatenate([r["tf"] for r in res])
+            # the baseline doubles as a live parity check of the timed run
+            order = np.concatenate([c for c in np.array_split(np.arange(len(idx)), cb["cores"] * 4) if len(c)])
+            tf_gpu = out["tf"].cpu().numpy()[idx[order]]
+            cb["max_rel_tf_diff_vs_gpu"] = float(np.max(np.abs(tf_cpu - tf_gpu) / tf_cpu))
+            line["cpu_baseline"] = cb
+        print(json.dumps(line), flush=True)
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

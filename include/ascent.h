@@ -123,7 +123,8 @@ int ascent_kkt_step(const ascent_params *p, int64_t batch, const ascent_opts *o,
                     int32_t *inertia_out, int device_id);
 
 /* Device time (ms) of the solve kernel of the most recent ascent_solve_batch on this device,
- * measured with HIP events on the launch stream; < 0 if none. */
+ * measured with HIP events recorded on the launch stream around the kernel; waits for that
+ * kernel to finish; < 0 if there was none. */
 double ascent_last_kernel_ms(int device_id);
 
 #ifdef __cplusplus

@@ -769,7 +769,7 @@ struct DeviceWs {
   double *ws = nullptr;
   size_t bytes = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  double last_ms = -1.0;
+  bool launched = false;
 };
 constexpr int MAX_DEV = 64;
 DeviceWs g_ws[MAX_DEV];
@@ -834,7 +834,14 @@ const char *ascent_strerror(int code) {
 
 double ascent_last_kernel_ms(int device_id) {
   if (device_id < 0 || device_id >= MAX_DEV) return -1.0;
-  return g_ws[device_id].last_ms;
+  std::lock_guard<std::mutex> lock(g_mu[device_id]);
+  DeviceWs &w = g_ws[device_id];
+  if (!w.launched) return -1.0;
+  if (hipSetDevice(device_id) != hipSuccess) return -1.0;
+  if (hipEventSynchronize(w.ev1) != hipSuccess) return -1.0;
+  float ms = -1.f;
+  if (hipEventElapsedTime(&ms, w.ev0, w.ev1) != hipSuccess) return -1.0;
+  return ms;
 }
 
 int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts *o,
@@ -885,6 +892,7 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
                      (int)o->warm_start, (int)o->max_iter, o->tol, mu0, dtraj, dtf, dstatus, diters, dblob);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(w.ev1, stream));
+  w.launched = true;
   if (!ptr_is_device) {
     if (traj_out) HIPCHK(hipMemcpyAsync(traj_out, dtraj, (size_t)10 * nt * batch * sizeof(double), hipMemcpyDeviceToHost, stream));
     if (sol_blob_out) HIPCHK(hipMemcpyAsync(sol_blob_out, dblob, rows * batch * sizeof(double), hipMemcpyDeviceToHost, stream));
@@ -892,11 +900,7 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
     HIPCHK(hipMemcpyAsync(status_out, dstatus, batch * sizeof(int), hipMemcpyDeviceToHost, stream));
     HIPCHK(hipMemcpyAsync(iters_out, diters, batch * sizeof(int), hipMemcpyDeviceToHost, stream));
   }
-  if (!ptr_is_device || !stream) {
-    HIPCHK(hipStreamSynchronize(stream));
-    float ms = -1.f;
-    if (hipEventElapsedTime(&ms, w.ev0, w.ev1) == hipSuccess) w.last_ms = ms;
-  }
+  if (!ptr_is_device || !stream) HIPCHK(hipStreamSynchronize(stream));
   return ASCENT_OK;
 }
 

@@ -128,3 +128,44 @@ def kkt_step(params, iterate: np.ndarray, mu, delta_w, nt: int = 200, device: in
     o = _opts(nt, 0, 1.0, 0, 0.0)
     _lib.check(L.ascent_kkt_step(_ptr(P), B, C.byref(o), _ptr(it), _ptr(mu), _ptr(dw), _ptr(step), _ptr(inertia), device))
     return step, inertia
+
+
+def solve_batch_torch(params_t, nt: int = 200, tol: float = 1e-9, max_iter: int = 300, guess_t=None,
+                      warm_start: int = 0, mu_init: float = 0.0, want_traj: bool = True, want_blob: bool = False,
+                      out: dict | None = None, sync: bool = False) -> dict:
+    """Device-resident variant: `params_t` is a torch float64 CUDA tensor (batch,16); all outputs are
+    torch CUDA tensors (allocated here unless passed in `out`).  Enqueues on torch's current stream
+    and returns without waiting unless sync=True.  torch is only the owner of device memory/streams."""
+    import torch
+    L = _lib.load()
+    if not (params_t.is_cuda and params_t.dtype == torch.float64 and params_t.is_contiguous()):
+        raise ValueError("params_t must be a contiguous float64 CUDA tensor")
+    B = params_t.shape[0]
+    dev = params_t.device
+    rows = blob_rows(nt)
+    out = out if out is not None else {}
+    def buf(name, shape, dtype):
+        t = out.get(name)
+        if t is None:
+            t = out[name] = torch.empty(shape, dtype=dtype, device=dev)
+        return t
+    tf = buf("tf", (B,), torch.float64)
+    status = buf("status", (B,), torch.int32)
+    iters = buf("iters", (B,), torch.int32)
+    traj = buf("traj", (10, nt, B), torch.float64) if want_traj else None
+    blob = buf("blob", (rows, B), torch.float64) if want_blob else None
+    o = _opts(nt, max_iter, tol, warm_start, mu_init)
+    stream = torch.cuda.current_stream(dev).cuda_stream
+    _lib.check(L.ascent_solve_batch(params_t.data_ptr(), B, C.byref(o),
+                                    guess_t.data_ptr() if guess_t is not None else None,
+                                    traj.data_ptr() if traj is not None else None, tf.data_ptr(), status.data_ptr(),
+                                    iters.data_ptr(), blob.data_ptr() if blob is not None else None,
+                                    dev.index or 0, C.c_void_p(stream), 1))
+    if sync:
+        torch.cuda.synchronize(dev)
+    return out
+
+
+def last_kernel_ms(device: int = 0) -> float:
+    """HIP-event time of the most recent solve kernel on `device` (waits for it)."""
+    return _lib.load().ascent_last_kernel_ms(device)

@@ -1,0 +1,88 @@
+"""CPU tests of the host logic and of the C-ABI library surface (no compute without a GPU)."""
+import ctypes as C
+import os
+import re
+
+import numpy as np
+import pytest
+
+import lunar_module_ascent_trajectory_optimiser_amd as A
+from lunar_module_ascent_trajectory_optimiser_amd import _lib, build
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def lib():
+    build.build()          # hipcc cross-compiles gfx950 without a GPU
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    hdr = open(os.path.join(ROOT, "include", "ascent.h")).read()
+    hdr = re.sub(r"/\*.*?\*/", "", hdr, flags=re.S)
+    names = set(re.findall(r"\b(ascent_[a-z_]+)\s*\(", hdr))
+    assert {"ascent_solve_batch", "ascent_eval_nodes", "ascent_kkt_step", "ascent_version",
+            "ascent_device_count", "ascent_strerror", "ascent_last_kernel_ms"} <= names
+    for n in names:
+        assert hasattr(lib, n), n
+    assert set(_lib.SYMBOLS) == names
+    assert lib.ascent_version() >= 100
+
+
+def test_struct_layouts_match_header():
+    assert C.sizeof(_lib.AscentParamsC) == 16 * 8
+    assert C.sizeof(_lib.AscentOptsC) == 32
+    assert tuple(n for n, _ in _lib.AscentParamsC._fields_) == A.PARAM_FIELDS
+
+
+def test_params_defaults_are_the_reference_constants():
+    p = A.AscentParams()      # /root/reference/Launch_Optimiser.py:38-75
+    assert (p.G, p.M, p.R0, p.Ft, p.M0, p.mdot, p.fuel_mass) == (6.674e-11, 7.346e22, 1738100.0, 15346.0, 4821.0, 5.053, 2376.0)
+    assert (p.ang_acc_max, p.r_peri, p.r_apo, p.T_scale) == (5e-4, 17703.0, 88615.0, 470.0)
+    assert abs(p.periapsis_v - 1654.3956154295) < 1e-6
+    assert A.blob_rows(200) == 21 * 199 + 10
+
+
+def test_sweeps_shapes_and_ranges():
+    S = A.sweep_isp_drymass()
+    assert S.shape == (4096, 16)
+    f = A.PARAM_FIELDS
+    isp = S[:, f.index("Ft")] / (S[:, f.index("mdot")] * 9.80665)
+    assert abs(isp.min() - 300) < 1e-9 and abs(isp.max() - 320) < 1e-9
+    dry = S[:, f.index("M0")] - S[:, f.index("fuel_mass")]
+    assert dry.min() == 2345 and dry.max() == 2545
+    S4 = A.sweep_config4(4, 4, 8, 8)
+    assert S4.shape == (4 * 4 * 64, 16)
+    assert abs(S4[:, f.index("r_apo")].min() - 70e3) < 1e-6 and abs(S4[:, f.index("r_apo")].max() - 105e3) < 1e-6
+    assert abs(S4[:, f.index("ang_acc_max")].min() - 3e-4) < 1e-12
+    # the full config-4 grid is 262 144 problems
+    assert 64 * 64 * 8 * 8 == 262144
+
+
+def test_product_fails_loudly_without_gpu(lib):
+    """No CPU fallback: without a device the solve raises instead of silently computing elsewhere."""
+    if lib.ascent_device_count() > 0:
+        pytest.skip("a GPU is present")
+    with pytest.raises(_lib.AscentLibraryError):
+        A.solve_batch(A.AscentParams())
+
+
+def test_argument_validation(lib):
+    o = _lib.AscentOptsC(n_nodes=200, scheme=0, max_iter=10, warm_start=0, tol=1e-8, mu_init=0.0)
+    assert lib.ascent_solve_batch(None, 1, C.byref(o), None, None, None, None, None, None, 0, None, 0) == -1
+    assert b"null" in lib.ascent_strerror(-1)
+    P = A.AscentParams().as_row()
+    o2 = _lib.AscentOptsC(n_nodes=200, scheme=1, max_iter=10, warm_start=0, tol=1e-8, mu_init=0.0)
+    rc = lib.ascent_solve_batch(P.ctypes.data_as(C.c_void_p), 1, C.byref(o2), None, None, None, None, None, None, 0, None, 0)
+    assert rc == -1 and b"scheme" in lib.ascent_strerror(rc)
+
+
+def test_product_does_not_import_oracle():
+    """The product package must never route through oracle/ (test infrastructure only)."""
+    pkg = os.path.join(ROOT, "lunar_module_ascent_trajectory_optimiser_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".hpp", ".cpp", ".h")):
+                src = open(os.path.join(dirpath, fn)).read()
+                assert "oracle" not in src.replace("# oracle-free", ""), fn

@@ -1,0 +1,192 @@
+"""CPU tests: the oracle against the reference's golden vectors (tests/golden/golden.json,
+transcribed from /root/reference/Numerical_results.png and PDF p30) and against itself
+(numpy generic sparse-LU interior point vs plain-C stage-structured one)."""
+import numpy as np
+import pytest
+
+from oracle.ascent_numpy import AscentNLP, Params, accel, solve_ip, v1_params
+
+
+@pytest.fixture(scope="module")
+def numpy_nominal():
+    nlp = AscentNLP(Params(), 200, 0)
+    v, lam, info = solve_ip(nlp, tol=1e-9)
+    assert info["status"] == "converged"
+    return nlp, v, lam, info
+
+
+def _check_current(out, golden):
+    g, tol = golden["current"], golden["tolerances"]
+    downrange = abs(g["final_x"])
+    speed = np.hypot(g["final_xdot"], g["final_ydot"])
+    assert abs(out["final_time"] - g["final_time"]) <= tol["final_time_rel"] * g["final_time"]
+    assert abs(out["final_x"] - g["final_x"]) <= tol["position_rel_of_downrange"] * downrange
+    assert abs(out["final_y"] - g["final_y"]) <= tol["position_rel_of_downrange"] * downrange
+    assert abs(out["final_xdot"] - g["final_xdot"]) <= tol["velocity_rel_of_speed"] * speed
+    assert abs(out["final_ydot"] - g["final_ydot"]) <= tol["velocity_rel_of_speed"] * speed
+    assert abs(out["final_xdoubledot"] - g["final_xdoubledot"]) <= tol["acceleration_rel"] * abs(g["final_xdoubledot"])
+    assert abs(out["final_ydoubledot"] - g["final_ydoubledot"]) <= tol["acceleration_rel"] * abs(g["final_ydoubledot"])
+
+
+def test_periapsis_velocity_constant(golden):
+    # Launch_Optimiser.py:75 prints periapsis_v (:179)
+    d = Params().derived()
+    assert abs(d["vper"] - golden["current"]["periapsis_v"]) < 1e-6
+
+
+def test_numpy_oracle_matches_golden_current(numpy_nominal, golden):
+    nlp, v, _, _ = numpy_nominal
+    _check_current(nlp.outputs(v), golden)
+
+
+def test_c_oracle_matches_golden_current(nominal_oracle_solution, golden):
+    p16, r = nominal_oracle_solution
+    S = p16[9]
+    tr = r["traj"][0]
+    out = dict(final_time=r["tf"][0] * p16[11], final_x=tr[0, -1] * S, final_y=tr[1, -1] * S,
+               final_xdot=tr[2, -1] * S, final_ydot=tr[3, -1] * S, final_xdoubledot=tr[4, -1] * S,
+               final_ydoubledot=tr[5, -1] * S)
+    _check_current(out, golden)
+
+
+def test_numpy_oracle_matches_golden_v1(golden):
+    """v1 script (PDF p26-30): angle is the MV, circular target, mass_scalar=2576 quirk."""
+    nlp = AscentNLP(v1_params(), 200, 1)
+    v, _, info = solve_ip(nlp, tol=1e-9, max_iter=300)
+    assert info["status"] == "converged"
+    o, g = nlp.outputs(v), golden["v1"]
+    assert abs(o["final_time"] - g["final_time"]) <= 1e-4 * g["final_time"]
+    assert abs(o["tf"] - g["tf"]) <= 1e-4 * g["tf"]
+    assert abs(-o["final_x"] - g["final_x_flipped"]) <= 1e-4 * g["final_x_flipped"]
+    assert abs(o["final_y"] - g["final_y"]) <= 1e-4 * g["final_x_flipped"]
+    assert abs(-o["final_xdot"] - g["final_xdot_flipped"]) <= 1e-4 * g["final_xdot_flipped"]
+    assert abs(o["final_ydot"] - g["final_ydot"]) <= 1e-4 * g["final_xdot_flipped"]
+    assert abs(-o["final_xdoubledot"] - g["final_xdoubledot_flipped"]) <= 2e-3 * g["final_xdoubledot_flipped"]
+    # plot facts (PDF p21,31): control jumps to ~35 deg in the first step and ends near 111 deg
+    ang = 3 * o["angle"] * 180 / np.pi
+    assert 33 < ang[1] < 37 and 109 < ang[-1] < 113
+
+
+def test_angle_profile_matches_reference_plot(numpy_nominal, golden):
+    """Angle_vs_Time.png: 0 -> ~68.7 deg near 98 s, dip ~67.3 deg near 115 s, 88.5 deg at the end."""
+    nlp, v, _, _ = numpy_nominal
+    o, q = nlp.outputs(v), golden["qualitative"]
+    t, th = o["t"], 3 * o["angle"] * 180 / np.pi
+    early = t < 130
+    ipk = np.argmax(np.where(t < 108, th, -1))
+    assert abs(th[ipk] - q["angle_peak1_deg"]) < 1.0 and abs(t[ipk] - q["angle_peak1_time_s"]) < 8
+    dip = np.argmin(np.where((t > t[ipk]) & early, th, 1e9))
+    assert abs(th[dip] - q["angle_dip_deg"]) < 1.0 and abs(t[dip] - q["angle_dip_time_s"]) < 8
+    assert abs(th[-1] - q["angle_final_deg"]) < 0.2
+    assert np.all(np.abs(o["angledoubledot"]) <= 1 + 1e-9)
+    assert (np.abs(o["angledoubledot"]) > 0.999).sum() >= 40       # the angular-acceleration cap is active
+
+
+def test_terminal_constraints_active(numpy_nominal):
+    nlp, v, _, _ = numpy_nominal
+    d = nlp.d
+    Wk, tf, s1, s2 = nlp.split(v)
+    x, y, vx, vy = Wk[-1, 0], Wk[-1, 1], Wk[-1, 2], Wk[-1, 3]
+    assert abs(np.hypot(x, y + d["rho0"]) - d["rhof"]) < 1e-7
+    assert abs(vx * vx + vy * vy - d["vp2"]) < 1e-9
+    assert abs((y + d["rho0"]) * vy + x * vx) < 1e-9
+    # mass is linear in time (Launch_Optimiser.py:123)
+    k = np.arange(1, nlp.K + 1)
+    assert np.allclose(Wk[:, 6], d["beta"] * nlp.h * nlp.P.T_scale * tf * k, rtol=0, atol=1e-10)
+
+
+def test_accel_derivatives_finite_difference():
+    rng = np.random.default_rng(3)
+    P = Params()
+    n = 50
+    x, y = rng.uniform(-17, 0, n), rng.uniform(-1, 1, n)
+    a, m = rng.uniform(0, 1.04, n), rng.uniform(0, 0.95, n)
+    px, py = rng.standard_normal(n), rng.standard_normal(n)
+    ax, ay, gax, gay, H = accel(x, y, a, m, P, px, py)
+    eps = 1e-6
+    args = [x, y, a, m]
+    order = [(0, 0), (0, 1), (0, 2), (0, 3), (1, 1), (1, 2), (1, 3), (2, 2), (2, 3), (3, 3)]
+    for j in range(4):
+        ap = [v.copy() for v in args]; am = [v.copy() for v in args]
+        ap[j] += eps; am[j] -= eps
+        axp, ayp, gxp, gyp = accel(*ap, P)
+        axm, aym, gxm, gym = accel(*am, P)
+        assert np.allclose((axp - axm) / (2 * eps), gax[:, j], rtol=1e-6, atol=1e-9)
+        assert np.allclose((ayp - aym) / (2 * eps), gay[:, j], rtol=1e-6, atol=1e-9)
+        for i in range(4):
+            fd = (px * (gxp[:, i] - gxm[:, i]) + py * (gyp[:, i] - gym[:, i])) / (2 * eps)
+            idx = order.index((min(i, j), max(i, j)))
+            assert np.allclose(fd, H[:, idx], rtol=1e-5, atol=1e-8)
+
+
+def test_c_accel_matches_numpy(coracle):
+    rng = np.random.default_rng(4)
+    P = Params()
+    n = 200
+    x, y = rng.uniform(-17, 0, n), rng.uniform(-1, 1, n)
+    a, m = rng.uniform(0, 1.04, n), rng.uniform(0, 0.95, n)
+    px, py = rng.standard_normal(n), rng.standard_normal(n)
+    ref = accel(x, y, a, m, P, px, py)
+    got = coracle.accel(coracle.pack_params(P), x, y, a, m, px, py)
+    for r, g in zip(ref, got):
+        assert np.allclose(r, g, rtol=1e-12, atol=1e-13)
+
+
+def test_c_oracle_agrees_with_numpy_oracle(numpy_nominal, nominal_oracle_solution):
+    nlp, v, _, _ = numpy_nominal
+    p16, r = nominal_oracle_solution
+    assert abs(v[nlp.itf] - r["tf"][0]) <= 1e-10 * r["tf"][0]
+    o, tr = nlp.outputs(v), r["traj"][0]
+    assert np.abs(o["x"] - tr[0]).max() < 1e-9 and np.abs(o["y"] - tr[1]).max() < 1e-9
+    assert np.abs(o["angle"] - tr[6]).max() < 1e-8 and np.abs(o["mass"] - tr[9]).max() < 1e-10
+
+
+def test_c_newton_step_matches_generic_sparse_lu(coracle):
+    """The C oracle's stage-wise (Riccati + 2x2 border) Newton step equals a generic sparse LU
+    solve of the full KKT matrix assembled by the numpy oracle."""
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    from conftest import random_interior_blob
+    P = Params(); nt = 60; K = nt - 1
+    p16 = coracle.pack_params(P)
+    nlp = AscentNLP(P, nt, 0)
+    blob = random_interior_blob(nt, 1, p16, coracle)
+    mu, dw = 0.03, 0.2
+    v = np.zeros(nlp.n); lam = np.zeros(nlp.m); zL = np.zeros(nlp.n); zU = np.zeros(nlp.n)
+    Wk = v[:8 * K].reshape(K, 8)
+    Wk[:, :7] = blob[:7 * K].reshape(K, 7); Wk[:, 7] = blob[7 * K:8 * K]
+    lam[:7 * K] = blob[8 * K:15 * K]
+    zb = blob[15 * K:21 * K].reshape(K, 6); sc = blob[21 * K:]
+    base = np.arange(K) * 8
+    zL[base + 4], zU[base + 4], zL[base + 6], zU[base + 6], zL[base + 7], zU[base + 7] = zb.T
+    v[nlp.itf], zL[nlp.itf], zU[nlp.itf] = sc[0], sc[1], sc[2]
+    v[nlp.is1], v[nlp.is2], zL[nlp.is1], zL[nlp.is2] = sc[3], sc[4], sc[5], sc[6]
+    lam[-3], lam[-2], lam[-1] = sc[7], sc[8], sc[9]
+    assert np.allclose(nlp.constraints(v), coracle.constraints(p16, nt, blob), atol=1e-14)
+    hasL, hasU = np.isfinite(nlp.lb), np.isfinite(nlp.ub)
+    dL = np.where(hasL, v - nlp.lb, 1.0); dU = np.where(hasU, nlp.ub - v, 1.0)
+    J = nlp.jacobian(v); W = nlp.hessian(v, lam)
+    Sig = np.where(hasL, zL / dL, 0) + np.where(hasU, zU / dU, 0)
+    gphi = nlp.grad_objective(v) - np.where(hasL, mu / dL, 0) + np.where(hasU, mu / dU, 0)
+    rhs = -np.concatenate([gphi + J.T @ lam, nlp.constraints(v)])
+    Kmat = sp.bmat([[W + sp.diags(Sig + dw), J.T], [J, None]], format="csc")
+    sol = spla.splu(Kmat).solve(rhs)
+    dx, dlam = sol[:nlp.n], sol[nlp.n:]
+    rc, step = coracle.newton_step(p16, nt, blob, mu, dw)
+    assert rc == 0
+    dW = dx[:8 * K].reshape(K, 8)
+    scale = max(1.0, np.abs(dx).max())
+    assert np.abs(step[:7 * K] - dW[:, :7].ravel()).max() < 1e-8 * scale
+    assert np.abs(step[7 * K:8 * K] - dW[:, 7]).max() < 1e-8 * scale
+    assert np.abs(step[8 * K:15 * K] - dlam[:7 * K]).max() < 1e-8 * max(1.0, np.abs(dlam).max())
+    assert abs(step[21 * K] - dx[nlp.itf]) < 1e-9 and np.allclose(step[21 * K + 7:21 * K + 10], dlam[-3:], rtol=1e-7, atol=1e-9)
+
+
+def test_c_oracle_sweep_corners_feasible(coracle):
+    """feasibility-check the four corners of the config-3 Isp x dry-mass box."""
+    from lunar_module_ascent_trajectory_optimiser_amd import sweep_isp_drymass
+    S = sweep_isp_drymass(2, 2)
+    r = coracle.solve_batch(S, 200, 300, 1e-9)
+    assert np.all(r["status"] == 0)
+    assert np.all(r["traj"][:, 9, -1] < 1.0)           # fuel not exhausted (mass <= 1, Launch_Optimiser.py:83)
+    assert np.all((r["tf"] > 0.7) & (r["tf"] < 1.2))
