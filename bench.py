@@ -50,10 +50,10 @@ def rank_params(batch: int, rank: int, world: int) -> np.ndarray:
         full = A.sweep_config4()
         return np.ascontiguousarray(full[rank * batch:(rank + 1) * batch])
     n = int(round(batch ** 0.5))
-    if n * n != batch:
-        raise SystemExit("--batch-per-gpu must be a perfect square (Isp x dry-mass grid) ")
+    while batch % n:
+        n -= 1
     base = A.AscentParams() if rank == 0 else A.AscentParams(r_apo=float(APO_KM[rank % 8]) * 1e3)
-    return A.sweep_isp_drymass(n, n, base=base)
+    return A.sweep_isp_drymass(n, batch // n, base=base)       # 4096 -> the 64 x 64 grid of config 3
 
 
 def cpu_baseline(params: np.ndarray, nt: int, tol: float, sample: int):

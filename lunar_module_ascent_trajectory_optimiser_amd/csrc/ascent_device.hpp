@@ -29,6 +29,36 @@ __host__ __device__ constexpr int sid(int i, int j) {
   return i <= j ? (i * 7 - (i * (i - 1)) / 2 + (j - i)) : (j * 7 - (j * (j - 1)) / 2 + (i - j));
 }
 
+// 1/x: hardware seed (v_rcp_f64) + two Newton steps, ~1 ulp; a full IEEE division costs three times
+// the instructions and the solver divides ~40 times per collocation step.
+ASC_DEV double rcp(double x) {
+  double r = __builtin_amdgcn_rcp(x);
+  r = fma(fma(-x, r, 1.0), r, r);
+  r = fma(fma(-x, r, 1.0), r, r);
+  return r;
+}
+
+// sin and cos of a bounded argument (|x| < ~1e5; the solver only passes 3*angle in [0, pi]):
+// Cody-Waite reduction by pi/2 and the classic degree-13/14 minimax kernels on [-pi/4, pi/4].
+ASC_DEV void sincos_bounded(double x, double &s, double &c) {
+  const double kf = rint(x * 0.63661977236758134308);
+  const int q = (int)kf;
+  double r = fma(-kf, 1.57079632679489655800e+00, x);
+  r = fma(-kf, 6.12323399573676603587e-17, r);
+  const double z = r * r;
+  const double ps = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08),
+                    2.75573137070700676789e-06), -1.98412698298579493134e-04), 8.33333333332248946124e-03),
+                    -1.66666666666666324348e-01);
+  const double sr = fma(z * r, ps, r);
+  const double pc = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09),
+                    -2.75573143513906633035e-07), 2.48015872894767294178e-05), -1.38888888888741095749e-03),
+                    4.16666666666666019037e-02);
+  const double cr = fma(z * z, pc, fma(-0.5, z, 1.0));
+  const double s1 = (q & 1) ? cr : sr, c1 = (q & 1) ? sr : cr;
+  s = (q & 2) ? -s1 : s1;
+  c = ((q + 1) & 2) ? -c1 : c1;
+}
+
 struct Der {  // constants derived from ascent_params (Launch_Optimiser.py:65,72-75,107-109)
   double rho0, rhof, vp2, gam, thr, alpha, mrate, ms, M0, T, aub, tlb, tub;
 };
@@ -66,9 +96,9 @@ ASC_DEV void accel(const Der &d, double x, double y, double a, double m, double 
   const double ir = rsqrt(r2);
   const double ex = xi * ir, ey = et * ir;
   double s, c;
-  sincos(3.0 * a, &s, &c);
+  sincos_bounded(3.0 * a, s, c);
   const double dx = ex * c - ey * s, dy = ey * c + ex * s;
-  const double imp = 1.0 / (d.M0 - d.ms * m);
+  const double imp = rcp(d.M0 - d.ms * m);
   const double th = d.thr * imp;
   const double g3 = d.gam * ir * ir * ir;
   ax = th * dx - g3 * xi;
@@ -111,7 +141,7 @@ ASC_DEV void accel(const Der &d, double x, double y, double a, double m, double 
 ASC_DEV void implicit_block(const double *G, double dt, double *E) {
   const double d2 = dt * dt;
   const double m11 = 1.0 - d2 * G[0], m12 = -d2 * G[1], m21 = -d2 * G[4], m22 = 1.0 - d2 * G[5];
-  const double idet = 1.0 / (m11 * m22 - m12 * m21);
+  const double idet = rcp(m11 * m22 - m12 * m21);
   E[0] = m22 * idet;
   E[1] = -m12 * idet;
   E[2] = -m21 * idet;

@@ -2,20 +2,27 @@
 // /root/reference/Launch_Optimiser.py, hand-written for MI355X (gfx950).  Replaces the
 // m.solve() call at Launch_Optimiser.py:177 (GEKKO -> APMonitor -> IPOPT/MUMPS).
 //
-// Kernel structure (one lane = one NLP, see ascent_device.hpp):
+// Kernel structure (one lane = one NLP, one 64-lane wavefront = one workgroup = one "tile" of 64 NLPs):
 //   k_solve       the whole interior-point loop; per iteration
-//                   pass E  KKT error (optimality test, barrier update)
-//                   pass B  evaluate defects/Jacobian/Hessian blocks of every step and factorise the
-//                           bordered block-tridiagonal KKT system backwards in time (Riccati form)
-//                   pass F  forward substitution: primal step, fraction-to-boundary, merit slope
-//                   pass A  adjoint substitution: multiplier step, bound-multiplier steps
-//                   pass T  merit function at trial points (backtracking)
-//                   pass U  accept the step
+//                   pass B   evaluate defects/Jacobian/Hessian blocks of every collocation step and
+//                            factorise the bordered block-tridiagonal KKT system backwards in time
+//                   pass F   forward substitution: primal step, fraction-to-boundary, merit slope
+//                   pass A   adjoint substitution: multiplier step, bound-multiplier steps
+//                   pass T   merit function at trial points (backtracking line search)
+//                   pass UE  accept the step and evaluate the KKT error of the new iterate (fused)
 //   k_eval_nodes  per-(step, problem) defects + Jacobian + Hessian blocks (parity surface)
 //   k_kkt_step    one Newton step at a caller-supplied iterate (parity surface)
+//
+// Workspace layout in HBM: [tile][step k][field][64 lanes] doubles.  A pass streams the step
+// records of its tile in time order (forwards or backwards); every access of a wavefront is one
+// contiguous 512-byte row whose address is a wave-uniform base plus the lane, so loads use scalar
+// base registers.  Each pass is written as  prefetch(next step) / compute(current step) / store,  so
+// the HBM latency of step k-1 is hidden behind the arithmetic of step k (there is one wavefront per
+// SIMD at these register counts, so there is no other wavefront to switch to).
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 
@@ -26,94 +33,65 @@ using namespace ascent;
 
 namespace {
 
-// ---------------------------------------------------------------------------------------------
-// workspace: rows of `B` doubles each (B = batch rounded up to the wave size)
-// ---------------------------------------------------------------------------------------------
-struct Layout {
-  int K;
-  long B;
-  long it, st;                         // iterate blob, step blob (21K+10 rows each)
-  long sg, se, sf, sh;                 // per-step G[8], E[4], F[7], H[10]
-  long rz, ru, gt, gu, cc;             // barrier-form dual residuals, tf-coupling column, defects
-  long rr, qa, qm;                     // R_k, Sigma_angle, Sigma_mass
-  long ka, k0;                         // Riccati gains kappa[7], kappa0[3]
-  long total;
-};
+// rows of one step record
+constexpr int R_Z = 0, R_U = 7, R_L = 8, R_ZB = 15;          // iterate: z[7] u lambda[7] zb[6]
+constexpr int R_DZ = 21, R_DU = 28, R_DL = 29, R_DZB = 36;   // step:    same order
+constexpr int R_G = 42, R_E = 50, R_H = 54, R_F = 64, R_C = 71, R_KA = 78, R_K0 = 85, R_ID = 88;
+constexpr int R_STAGE = 94;
+constexpr int WAVE = 64;
 
-__host__ __device__ inline Layout make_layout(int K, long B) {
-  Layout L;
-  L.K = K;
-  L.B = B;
-  long o = 0;
-  auto take = [&](long n) { long r = o; o += n; return r; };
-  L.it = take(21L * K + NSC);
-  L.st = take(21L * K + NSC);
-  L.sg = take(8L * K);
-  L.se = take(4L * K);
-  L.sf = take(7L * K);
-  L.sh = take(10L * K);
-  L.rz = take(7L * K);
-  L.ru = take(K);
-  L.gt = take(7L * K);
-  L.gu = take(K);
-  L.cc = take(7L * K);
-  L.rr = take(K);
-  L.qa = take(K);
-  L.qm = take(K);
-  L.ka = take(7L * K);
-  L.k0 = take(3L * K);
-  L.total = o;
-  return L;
-}
+__host__ __device__ inline size_t tile_doubles(int K) { return (size_t)K * R_STAGE * WAVE; }
 
-// per-lane view of the workspace
-struct Ctx {
-  double *ws;  // already offset by the problem index
-  long B;
+typedef __attribute__((address_space(1))) double gdbl;   // HBM (global address space) double
+
+struct W {  // one lane's view of its tile
+  gdbl *tile;  // wave-uniform base of this wavefront's tile
   int K;
   double h;
-  Layout L;
   Der d;
-  ASC_DEV double &at(long off, long r) const { return ws[(off + r) * B]; }
-  // iterate blob rows
-  ASC_DEV double &z(int k, int f) const { return at(L.it, 7L * k + f); }
-  ASC_DEV double &u(int k) const { return at(L.it, 7L * K + k); }
-  ASC_DEV double &lam(int k, int f) const { return at(L.it, 8L * K + 7L * k + f); }
-  ASC_DEV double &zb(int k, int b) const { return at(L.it, 15L * K + 6L * k + b); }
-  ASC_DEV double &sc(int j) const { return at(L.it, 21L * K + j); }
-  ASC_DEV double &dz(int k, int f) const { return at(L.st, 7L * k + f); }
-  ASC_DEV double &du(int k) const { return at(L.st, 7L * K + k); }
-  ASC_DEV double &dlam(int k, int f) const { return at(L.st, 8L * K + 7L * k + f); }
-  ASC_DEV double &dzb(int k, int b) const { return at(L.st, 15L * K + 6L * k + b); }
-  ASC_DEV double &dsc(int j) const { return at(L.st, 21L * K + j); }
 };
+
+// A pointer / integer that is the same in all 64 lanes, moved to scalar registers so that the
+// compiler addresses HBM as  scalar base + lane  (global_load ... s[base:base+1]).
+ASC_DEV gdbl *uniform(gdbl *p) {
+  const unsigned long long v = (unsigned long long)p;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (gdbl *)(((unsigned long long)hi << 32) | lo);
+}
+ASC_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+
+struct Tile {  // uniform tile base + this lane
+  gdbl *base;
+  unsigned lane;
+  ASC_DEV explicit Tile(const W &w) : base(uniform(w.tile)), lane(threadIdx.x) {}
+  ASC_DEV gdbl *st(int k) const { return base + (size_t)k * (R_STAGE * WAVE); }
+};
+#define ROW(p, r) (p)[(r) * WAVE + t_.lane]
+#define ASC_PASS __device__ __noinline__   // one register allocation per pass
+
+template <int N>
+ASC_DEV void ldn(const Tile &t_, const gdbl *p, int r0, double *v) {
+  ASC_UNROLL
+  for (int i = 0; i < N; i++) v[i] = ROW(p, r0 + i);
+}
+template <int N>
+ASC_DEV void stn(const Tile &t_, gdbl *p, int r0, const double *v) {
+  ASC_UNROLL
+  for (int i = 0; i < N; i++) ROW(p, r0 + i) = v[i];
+}
+template <int N>
+ASC_DEV void cpy(double *dst, const double *src) {
+  ASC_UNROLL
+  for (int i = 0; i < N; i++) dst[i] = src[i];
+}
 
 // scalars of the iterate / step kept in registers
 struct Scal {
   double th, zlt, zut, s1, s2, zs1, zs2, nu3, nu1, nu2;
 };
-ASC_DEV Scal load_scal(const Ctx &c, long off) {
-  Scal s;
-  const long b = 21L * c.K;
-  s.th = c.at(off, b + S_TH); s.zlt = c.at(off, b + S_ZLT); s.zut = c.at(off, b + S_ZUT);
-  s.s1 = c.at(off, b + S_S1); s.s2 = c.at(off, b + S_S2); s.zs1 = c.at(off, b + S_ZS1);
-  s.zs2 = c.at(off, b + S_ZS2); s.nu3 = c.at(off, b + S_NU3); s.nu1 = c.at(off, b + S_NU1);
-  s.nu2 = c.at(off, b + S_NU2);
-  return s;
-}
-ASC_DEV void store_scal(const Ctx &c, long off, const Scal &s) {
-  const long b = 21L * c.K;
-  c.at(off, b + S_TH) = s.th; c.at(off, b + S_ZLT) = s.zlt; c.at(off, b + S_ZUT) = s.zut;
-  c.at(off, b + S_S1) = s.s1; c.at(off, b + S_S2) = s.s2; c.at(off, b + S_ZS1) = s.zs1;
-  c.at(off, b + S_ZS2) = s.zs2; c.at(off, b + S_NU3) = s.nu3; c.at(off, b + S_NU1) = s.nu1;
-  c.at(off, b + S_NU2) = s.nu2;
-}
 
-// ---------------------------------------------------------------------------------------------
-// pass E: optimality error pieces.  E(mu) = max(rd/sd, cinf, comp(mu)/sd) with
-// comp(mu) = max(|pmax - mu|, |pmin - mu|) over all complementarity products.
-// ---------------------------------------------------------------------------------------------
-struct ErrParts {
+struct ErrParts {  // E(mu) = max(rd/sd, cinf, comp(mu)/sd), comp(mu) from the extreme complementarity products
   double rd, cinf, pmin, pmax, sd;
   ASC_DEV double err(double mu) const {
     const double comp = fmax(fabs(pmax - mu), fabs(pmin - mu));
@@ -121,34 +99,122 @@ struct ErrParts {
   }
 };
 
-ASC_DEV ErrParts pass_error(const Ctx &c, const Scal &s) {
-  const Der &d = c.d;
-  const int K = c.K;
-  const double hT = c.h * d.T, dt = hT * s.th;
+ASC_DEV double clipz(double zv, double dist, double mu) {
+  return fmin(fmax(zv, mu / (1e10 * dist)), 1e10 * mu / dist);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Loop skeleton shared by all passes: the step records are double-buffered in registers (A, B);
+// while step k is being computed the loads of the next step are already in flight.  Unrolled by two
+// so that the buffers swap roles without register copies.
+// ---------------------------------------------------------------------------------------------
+#define ASC_SWEEP_BACKWARD(IN, LOAD, BODY)                 \
+  {                                                        \
+    IN bufA, bufB;                                         \
+    LOAD(K - 1, bufA);                                     \
+    int k = K - 1;                                         \
+    for (; k >= 1; k -= 2) {                               \
+      LOAD(k - 1, bufB);                                   \
+      BODY(bufA, k);                                       \
+      if (k >= 2) LOAD(k - 2, bufA);                       \
+      BODY(bufB, k - 1);                                   \
+    }                                                      \
+    if (k == 0) BODY(bufA, 0);                             \
+  }
+#define ASC_SWEEP_FORWARD(IN, LOAD, BODY)                  \
+  {                                                        \
+    IN bufA, bufB;                                         \
+    LOAD(0, bufA);                                         \
+    int k = 0;                                             \
+    for (; k + 1 < K; k += 2) {                            \
+      LOAD(k + 1, bufB);                                   \
+      BODY(bufA, k);                                       \
+      if (k + 2 < K) LOAD(k + 2, bufA);                    \
+      BODY(bufB, k + 1);                                   \
+    }                                                      \
+    if (k == K - 1) BODY(bufA, k);                         \
+  }
+
+// ---------------------------------------------------------------------------------------------
+// pass UE: (optionally) accept the step  it += alpha*step  and evaluate the KKT error pieces of the
+// resulting iterate, backwards in time.  `s` holds the already-updated scalars.
+// ---------------------------------------------------------------------------------------------
+struct InUE {
+  double zp[7], dzp[7], l[7], dl[7], zb[6], dzb[6], u, du;
+};
+template <bool UPDATE>
+ASC_DEV void loadUE(const Tile &t_, int k, InUE &in) {
+  const gdbl *sp = t_.st(k);
+  ldn<7>(t_, sp, R_L, in.l);
+  ldn<6>(t_, sp, R_ZB, in.zb);
+  in.u = ROW(sp, R_U);
+  if (UPDATE) {
+    ldn<7>(t_, sp, R_DL, in.dl);
+    ldn<6>(t_, sp, R_DZB, in.dzb);
+    in.du = ROW(sp, R_DU);
+  }
+  if (k > 0) {
+    const gdbl *spp = t_.st(k - 1);
+    ldn<7>(t_, spp, R_Z, in.zp);
+    if (UPDATE) ldn<7>(t_, spp, R_DZ, in.dzp);
+  } else {
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) { in.zp[i] = 0.0; in.dzp[i] = 0.0; }
+  }
+}
+
+template <bool UPDATE>
+ASC_PASS ErrParts pass_update_error(const W &w, const Scal &s, double alpha, double adu, double mu) {
+  const Der &d = w.d;
+  const Tile t_(w);
+  const int K = uniform(w.K);
+  const double hT = w.h * d.T, dt = hT * s.th;
   double rd = 0.0, cinf = 0.0, pmin = 1e300, pmax = -1e300, l1 = 0.0, zsum = 0.0, rth = 1.0;
   double z[7], ln[7];
+  {
+    gdbl *sp = t_.st(K - 1);
+    ldn<7>(t_, sp, R_Z, z);
+    if (UPDATE) {
+      double dz[7];
+      ldn<7>(t_, sp, R_DZ, dz);
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) z[i] += alpha * dz[i];
+      stn<7>(t_, sp, R_Z, z);
+    }
+  }
   ASC_UNROLL
-  for (int i = 0; i < 7; i++) { z[i] = c.z(K - 1, i); ln[i] = 0.0; }
-  for (int k = K - 1; k >= 0; k--) {
-    double zp[7], l[7], zb[6], G[8], F[7], fl[7], ax, ay;
-    ASC_UNROLL
-    for (int i = 0; i < 7; i++) { zp[i] = k ? c.z(k - 1, i) : 0.0; l[i] = c.lam(k, i); }
-    ASC_UNROLL
-    for (int b = 0; b < 6; b++) zb[b] = c.zb(k, b);
-    const double u = c.u(k);
+  for (int i = 0; i < 7; i++) ln[i] = 0.0;
+  const double mlo = mu * 1e-10, mhi = mu * 1e10;
+  auto body = [&](InUE &cur, int k) __attribute__((always_inline)) {
+    gdbl *sp = t_.st(k);
+    if (UPDATE) {
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) { cur.zp[i] += alpha * cur.dzp[i]; cur.l[i] += alpha * cur.dl[i]; }
+      cur.u += alpha * cur.du;
+      const double dist[6] = {z[IA], d.aub - z[IA], z[IM], 1.0 - z[IM], cur.u + 1.0, 1.0 - cur.u};
+      ASC_UNROLL
+      for (int b = 0; b < 6; b++) {   // keep z within [mu/(k d), k mu/d], k = 1e10
+        const double id = rcp(dist[b]);
+        cur.zb[b] = fmin(fmax(cur.zb[b] + adu * cur.dzb[b], mlo * id), mhi * id);
+      }
+      if (k > 0) stn<7>(t_, t_.st(k - 1), R_Z, cur.zp);
+      stn<7>(t_, sp, R_L, cur.l);
+      stn<6>(t_, sp, R_ZB, cur.zb);
+      ROW(sp, R_U) = cur.u;
+    }
+    double G[8], F[7], fl[7], r[7], ax, ay;
     accel<1>(d, z[IX], z[IY], z[IA], z[IM], 0.0, 0.0, ax, ay, G, nullptr);
-    rhs_f(d, z, u, ax, ay, F);
-    fzt_lambda(G, l, fl);
-    double r[7];
+    rhs_f(d, z, cur.u, ax, ay, F);
+    fzt_lambda(G, cur.l, fl);
     ASC_UNROLL
     for (int i = 0; i < 7; i++) {
-      r[i] = l[i] - dt * fl[i] - ln[i];
-      rth -= hT * F[i] * l[i];
-      l1 += fabs(l[i]);
-      cinf = fmax(cinf, fabs(z[i] - zp[i] - dt * F[i]));
+      r[i] = cur.l[i] - dt * fl[i] - ln[i];
+      rth -= hT * F[i] * cur.l[i];
+      l1 += fabs(cur.l[i]);
+      cinf = fmax(cinf, fabs(z[i] - cur.zp[i] - dt * F[i]));
     }
-    r[IA] += zb[1] - zb[0];
-    r[IM] += zb[3] - zb[2];
+    r[IA] += cur.zb[1] - cur.zb[0];
+    r[IM] += cur.zb[3] - cur.zb[2];
     if (k == K - 1) {
       const Terminal t = terminal_eval(d, z);
       r[IX] += s.nu3 * t.e3g[0] + s.nu1 * t.g1g[0];
@@ -159,18 +225,21 @@ ASC_DEV ErrParts pass_error(const Ctx &c, const Scal &s) {
     }
     ASC_UNROLL
     for (int i = 0; i < 7; i++) rd = fmax(rd, fabs(r[i]));
-    rd = fmax(rd, fabs(-dt * d.alpha * l[IW] - zb[4] + zb[5]));
-    const double lo[3] = {z[IA], z[IM], u + 1.0}, up[3] = {d.aub - z[IA], 1.0 - z[IM], 1.0 - u};
+    rd = fmax(rd, fabs(-dt * d.alpha * cur.l[IW] - cur.zb[4] + cur.zb[5]));
+    const double lo[3] = {z[IA], z[IM], cur.u + 1.0}, up[3] = {d.aub - z[IA], 1.0 - z[IM], 1.0 - cur.u};
     ASC_UNROLL
     for (int b = 0; b < 3; b++) {
-      const double p1 = lo[b] * zb[2 * b], p2 = up[b] * zb[2 * b + 1];
+      const double p1 = lo[b] * cur.zb[2 * b], p2 = up[b] * cur.zb[2 * b + 1];
       pmin = fmin(pmin, fmin(p1, p2));
       pmax = fmax(pmax, fmax(p1, p2));
-      zsum += zb[2 * b] + zb[2 * b + 1];
+      zsum += cur.zb[2 * b] + cur.zb[2 * b + 1];
     }
-    ASC_UNROLL
-    for (int i = 0; i < 7; i++) { ln[i] = l[i]; z[i] = zp[i]; }
-  }
+    cpy<7>(ln, cur.l);
+    cpy<7>(z, cur.zp);
+  };
+#define LD_(k_, buf_) loadUE<UPDATE>(t_, k_, buf_)
+  ASC_SWEEP_BACKWARD(InUE, LD_, body)
+#undef LD_
   rd = fmax(rd, fabs(rth - s.zlt + s.zut));
   rd = fmax(rd, fmax(fabs(-s.nu1 - s.zs1), fabs(-s.nu2 - s.zs2)));
   const double pr[4] = {(s.th - d.tlb) * s.zlt, (d.tub - s.th) * s.zut, s.s1 * s.zs1, s.s2 * s.zs2};
@@ -186,108 +255,109 @@ ASC_DEV ErrParts pass_error(const Ctx &c, const Scal &s) {
 
 // ---------------------------------------------------------------------------------------------
 // pass B: evaluate + backward factorisation.  Returns 0, or 1 when the inertia is wrong.
-// On success the border unknowns (dtheta, dnu3) are in ds; c1 = ||c||_1.
 // ---------------------------------------------------------------------------------------------
 struct BorderOut {
-  double dth, dnu3, c1, sig1, sig2, rs1, rs2, sth;
+  double dth, dnu3, c1, sig1, sig2, rs1, rs2;
 };
+struct InB {
+  double zp[7], l[7], zb[6], u;
+};
+ASC_DEV void loadB(const Tile &t_, int k, InB &in) {
+  const gdbl *sp = t_.st(k);
+  ldn<7>(t_, sp, R_L, in.l);
+  ldn<6>(t_, sp, R_ZB, in.zb);
+  in.u = ROW(sp, R_U);
+  if (k > 0) {
+    ldn<7>(t_, t_.st(k - 1), R_Z, in.zp);
+  } else {
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) in.zp[i] = 0.0;
+  }
+}
 
-ASC_DEV int pass_backward(const Ctx &c, const Scal &s, double mu, double dw, BorderOut &out) {
-  const Der &d = c.d;
-  const int K = c.K;
-  const double hT = c.h * d.T, dt = hT * s.th, be = dt * d.alpha;
+ASC_PASS int pass_backward(const W &w, const Scal &s, double mu, double dw, BorderOut &out) {
+  const Der &d = w.d;
+  const Tile t_(w);
+  const int K = uniform(w.K);
+  const double hT = w.h * d.T, dt = hT * s.th, be = dt * d.alpha;
   double P[28], p0[7], p1[7], p2[7];
   ASC_UNROLL
   for (int i = 0; i < 28; i++) P[i] = 0.0;
   ASC_UNROLL
   for (int i = 0; i < 7; i++) { p0[i] = p1[i] = p2[i] = 0.0; }
-  double S10 = 0.0, S11 = 0.0, S12 = 0.0, S20 = 0.0, S22 = 0.0, rth = 1.0, c1 = 0.0;
+  double S10 = 0.0, S11 = 0.0, S12 = 0.0, S20 = 0.0, S22 = 0.0, rth = 1.0;
   double z[7], ln[7];
+  ldn<7>(t_, t_.st(K - 1), R_Z, z);
   ASC_UNROLL
-  for (int i = 0; i < 7; i++) { z[i] = c.z(K - 1, i); ln[i] = 0.0; }
-  Terminal tm = terminal_eval(d, z);
-  const double sig1 = s.zs1 / s.s1 + dw, sig2 = s.zs2 / s.s2 + dw;
-  const double rs1 = -mu / s.s1 - s.nu1, rs2 = -mu / s.s2 - s.nu2;
+  for (int i = 0; i < 7; i++) ln[i] = 0.0;
+  const Terminal tm = terminal_eval(d, z);
+  const double is1 = rcp(s.s1), is2 = rcp(s.s2);
+  const double sig1 = s.zs1 * is1 + dw, sig2 = s.zs2 * is2 + dw;
+  const double rs1 = -mu * is1 - s.nu1, rs2 = -mu * is2 - s.nu2;
   const double cg1 = tm.g1 - s.s1, cg2 = tm.g2 - s.s2;
-  c1 = fabs(tm.e3) + fabs(cg1) + fabs(cg2);
-  for (int k = K - 1; k >= 0; k--) {
-    double zp[7], l[7], zb[6], G[8], E[4], H[10], F[7], fl[7], ax, ay;
-    ASC_UNROLL
-    for (int i = 0; i < 7; i++) { zp[i] = k ? c.z(k - 1, i) : 0.0; l[i] = c.lam(k, i); }
-    ASC_UNROLL
-    for (int b = 0; b < 6; b++) zb[b] = c.zb(k, b);
-    const double u = c.u(k);
-    accel<2>(d, z[IX], z[IY], z[IA], z[IM], -dt * l[IVX], -dt * l[IVY], ax, ay, G, H);
-    rhs_f(d, z, u, ax, ay, F);
+  double c1 = fabs(tm.e3) + fabs(cg1) + fabs(cg2);
+  int bad = 0;
+  auto body = [&](InB &cur, int k) __attribute__((always_inline)) {
+    gdbl *sp = t_.st(k);
+    double G[8], E[4], H[10], F[7], fl[7], ax, ay;
+    accel<2>(d, z[IX], z[IY], z[IA], z[IM], -dt * cur.l[IVX], -dt * cur.l[IVY], ax, ay, G, H);
+    rhs_f(d, z, cur.u, ax, ay, F);
     implicit_block(G, dt, E);
-    fzt_lambda(G, l, fl);
+    fzt_lambda(G, cur.l, fl);
     double rz[7], gt[7], cc[7];
     ASC_UNROLL
     for (int i = 0; i < 7; i++) {
-      rz[i] = l[i] - dt * fl[i] - ln[i];
+      rz[i] = cur.l[i] - dt * fl[i] - ln[i];
       gt[i] = -hT * fl[i];
-      cc[i] = z[i] - zp[i] - dt * F[i];
+      cc[i] = z[i] - cur.zp[i] - dt * F[i];
       c1 += fabs(cc[i]);
-      rth -= hT * F[i] * l[i];
+      rth -= hT * F[i] * cur.l[i];
     }
-    const double a = z[IA], m = z[IM];
-    rz[IA] += -mu / a + mu / (d.aub - a);
-    rz[IM] += -mu / m + mu / (1.0 - m);
-    const double ru = -be * l[IW] - mu / (u + 1.0) + mu / (1.0 - u);
-    const double gu = -hT * d.alpha * l[IW];
-    const double R = zb[4] / (u + 1.0) + zb[5] / (1.0 - u) + dw;
-    const double qa = zb[0] / a + zb[1] / (d.aub - a), qm = zb[2] / m + zb[3] / (1.0 - m);
-    // N = Q_k + P_{k+1}
-    double N[28];
+    // reciprocal distances to the bounds of angle, mass, u (reused by passes F and A)
+    const double a = z[IA], m = z[IM], u = cur.u;
+    const double id[6] = {rcp(a), rcp(d.aub - a), rcp(m), rcp(1.0 - m), rcp(u + 1.0), rcp(1.0 - u)};
+    stn<6>(t_, sp, R_ID, id);
+    rz[IA] += mu * (id[1] - id[0]);
+    rz[IM] += mu * (id[3] - id[2]);
+    const double ru = -be * cur.l[IW] + mu * (id[5] - id[4]);
+    const double gu = -hT * d.alpha * cur.l[IW];
+    const double R = cur.zb[4] * id[4] + cur.zb[5] * id[5] + dw;
+    const double qa = cur.zb[0] * id[0] + cur.zb[1] * id[1], qm = cur.zb[2] * id[2] + cur.zb[3] * id[3];
+    // N = Q_k + P_{k+1}, built in place in P
+    P[sid(IX, IX)] += H[0]; P[sid(IX, IY)] += H[1]; P[sid(IX, IA)] += H[2]; P[sid(IX, IM)] += H[3];
+    P[sid(IY, IY)] += H[4]; P[sid(IY, IA)] += H[5]; P[sid(IY, IM)] += H[6];
+    P[sid(IA, IA)] += H[7] + qa; P[sid(IA, IM)] += H[8]; P[sid(IM, IM)] += H[9] + qm;
     ASC_UNROLL
-    for (int i = 0; i < 28; i++) N[i] = P[i];
-    N[sid(IX, IX)] += H[0]; N[sid(IX, IY)] += H[1]; N[sid(IX, IA)] += H[2]; N[sid(IX, IM)] += H[3];
-    N[sid(IY, IY)] += H[4]; N[sid(IY, IA)] += H[5]; N[sid(IY, IM)] += H[6];
-    N[sid(IA, IA)] += H[7] + qa; N[sid(IA, IM)] += H[8]; N[sid(IM, IM)] += H[9] + qm;
-    ASC_UNROLL
-    for (int i = 0; i < 7; i++) N[sid(i, i)] += dw;
+    for (int i = 0; i < 7; i++) P[sid(i, i)] += dw;
     if (k == K - 1) {
-      terminal_hessian(N, tm, s.nu3, s.nu1, s.nu2, sig1, sig2);
+      terminal_hessian(P, tm, s.nu3, s.nu1, s.nu2, sig1, sig2);
       const double w1 = s.nu1 + sig1 * cg1 + rs1, w2 = s.nu2 + sig2 * cg2 + rs2;
       rz[IX] += s.nu3 * tm.e3g[0] + w1 * tm.g1g[0];
       rz[IY] += s.nu3 * tm.e3g[1] + w1 * tm.g1g[1];
       rz[IVX] += s.nu3 * tm.e3g[2] + w2 * tm.g2g[0];
       rz[IVY] += s.nu3 * tm.e3g[3] + w2 * tm.g2g[1];
     }
-    // stage data needed by the forward / adjoint passes
-    ASC_UNROLL
-    for (int i = 0; i < 8; i++) c.at(c.L.sg, 8L * k + i) = G[i];
-    ASC_UNROLL
-    for (int i = 0; i < 4; i++) c.at(c.L.se, 4L * k + i) = E[i];
-    ASC_UNROLL
-    for (int i = 0; i < 10; i++) c.at(c.L.sh, 10L * k + i) = H[i];
-    ASC_UNROLL
-    for (int i = 0; i < 7; i++) {
-      c.at(c.L.sf, 7L * k + i) = F[i];
-      c.at(c.L.rz, 7L * k + i) = rz[i];
-      c.at(c.L.gt, 7L * k + i) = gt[i];
-      c.at(c.L.cc, 7L * k + i) = cc[i];
-    }
-    c.at(c.L.ru, k) = ru; c.at(c.L.gu, k) = gu; c.at(c.L.rr, k) = R;
-    c.at(c.L.qa, k) = qa; c.at(c.L.qm, k) = qm;
+    stn<8>(t_, sp, R_G, G);
+    stn<4>(t_, sp, R_E, E);
+    stn<10>(t_, sp, R_H, H);
+    stn<7>(t_, sp, R_F, F);
+    stn<7>(t_, sp, R_C, cc);
     // M = A^-T N A^-1 (in place), pivot, gain, P_k
-    congruence(N, G, E, dt);
-    const double D = R + be * be * N[sid(IW, IW)];
-    if (!(D > 0.0)) return 1;
-    const double iD = 1.0 / D;
+    congruence(P, G, E, dt);
+    const double D = R + be * be * P[sid(IW, IW)];
+    if (!(D > 0.0)) bad = 1;
+    const double iD = rcp(D);
     double mw[7], kap[7];
     ASC_UNROLL
-    for (int i = 0; i < 7; i++) { mw[i] = be * N[sid(i, IW)]; kap[i] = mw[i] * iD; }
+    for (int i = 0; i < 7; i++) { mw[i] = be * P[sid(i, IW)]; kap[i] = mw[i] * iD; }
     ASC_UNROLL
     for (int i = 0; i < 7; i++) {
       ASC_UNROLL
-      for (int j = i; j < 7; j++) P[sid(i, j)] = N[sid(i, j)] - mw[i] * kap[j];
+      for (int j = i; j < 7; j++) P[sid(i, j)] -= mw[i] * kap[j];
     }
-    ASC_UNROLL
-    for (int i = 0; i < 7; i++) c.at(c.L.ka, 7L * k + i) = kap[i];
+    stn<7>(t_, sp, R_KA, kap);
     // three right-hand sides (0: residual, 1: -B_theta, 2: -B_nu3)
-    double n[7], nt[7], q0[7], q1[7], q2[7], k00, k01, k02, rc1[7], Prc[7];
-    // rhs 0
+    double n[7], nt[7], q0[7], q1[7], rc1[7], Prc[7], k00, k01, k02;
     ASC_UNROLL
     for (int i = 0; i < 7; i++) n[i] = -rz[i] + p0[i];
     solveAT(G, E, dt, n, nt);
@@ -297,7 +367,6 @@ ASC_DEV int pass_backward(const Ctx &c, const Scal &s, double mu, double dw, Bor
     symv(P, n, Prc);
     ASC_UNROLL
     for (int i = 0; i < 7; i++) p0[i] = q0[i] - Prc[i];
-    // rhs 1
     ASC_UNROLL
     for (int i = 0; i < 7; i++) n[i] = -gt[i] + p1[i];
     solveAT(G, E, dt, n, nt);
@@ -307,117 +376,160 @@ ASC_DEV int pass_backward(const Ctx &c, const Scal &s, double mu, double dw, Bor
     symv(P, rc1, Prc);
     ASC_UNROLL
     for (int i = 0; i < 7; i++) p1[i] = q1[i] - Prc[i];
-    // rhs 2 (only the last node has a direct term; no defect / control part)
-    ASC_UNROLL
-    for (int i = 0; i < 7; i++) n[i] = p2[i];
+    cpy<7>(n, p2);
     if (k == K - 1) { n[IX] -= tm.e3g[0]; n[IY] -= tm.e3g[1]; n[IVX] -= tm.e3g[2]; n[IVY] -= tm.e3g[3]; }
     solveAT(G, E, dt, n, nt);
     k02 = be * nt[IW] * iD;
     ASC_UNROLL
-    for (int i = 0; i < 7; i++) { q2[i] = nt[i] - mw[i] * k02; p2[i] = q2[i]; }
-    c.at(c.L.k0, 3L * k) = k00; c.at(c.L.k0, 3L * k + 1) = k01; c.at(c.L.k0, 3L * k + 2) = k02;
-    // Schur-complement entries S_ij = rho_i' K0^-1 rho_j accumulated stage by stage
-    double a10 = D * k01 * k00, a11 = D * k01 * k01, a12 = D * k01 * k02, a20 = D * k02 * k00,
-           a22 = D * k02 * k02;
+    for (int i = 0; i < 7; i++) p2[i] = nt[i] - mw[i] * k02;   // q2 = p2 (no defect part)
+    ROW(sp, R_K0) = k00; ROW(sp, R_K0 + 1) = k01; ROW(sp, R_K0 + 2) = k02;
+    // Schur-complement entries S_ij = rho_i' K0^-1 rho_j accumulated step by step
+    double a10 = D * k01 * k00, a11 = D * k01 * k01, a12 = D * k01 * k02, a20 = D * k02 * k00;
     ASC_UNROLL
     for (int i = 0; i < 7; i++) {
       a10 += 0.5 * (rc1[i] * (q0[i] + p0[i]) - cc[i] * (q1[i] + p1[i]));
       a11 += rc1[i] * (q1[i] + p1[i]);
-      a12 += 0.5 * rc1[i] * (q2[i] + p2[i]);
-      a20 += -0.5 * cc[i] * (q2[i] + p2[i]);
+      a12 += rc1[i] * p2[i];
+      a20 -= cc[i] * p2[i];
     }
-    S10 += a10; S11 += a11; S12 += a12; S20 += a20; S22 += a22;
-    ASC_UNROLL
-    for (int i = 0; i < 7; i++) { ln[i] = l[i]; z[i] = zp[i]; }
-  }
-  rth += -mu / (s.th - d.tlb) + mu / (d.tub - s.th);
-  const double sth = s.zlt / (s.th - d.tlb) + s.zut / (d.tub - s.th) + dw;
+    S10 += a10; S11 += a11; S12 += a12; S20 += a20; S22 += D * k02 * k02;
+    cpy<7>(ln, cur.l);
+    cpy<7>(z, cur.zp);
+  };
+#define LD_(k_, buf_) loadB(t_, k_, buf_)
+  ASC_SWEEP_BACKWARD(InB, LD_, body)
+#undef LD_
+  if (bad) return 1;
+  const double itl = rcp(s.th - d.tlb), itu = rcp(d.tub - s.th);
+  rth += mu * (itu - itl);
+  const double sth = s.zlt * itl + s.zut * itu + dw;
   const double a11 = sth - S11, a12 = -S12, a22 = -S22;
   const double b1 = -rth + S10, b2 = -tm.e3 + S20;
   const double det = a11 * a22 - a12 * a12;
   if (!(det < 0.0)) return 1;
-  out.dth = (b1 * a22 - a12 * b2) / det;
-  out.dnu3 = (a11 * b2 - a12 * b1) / det;
-  out.c1 = c1; out.sig1 = sig1; out.sig2 = sig2; out.rs1 = rs1; out.rs2 = rs2; out.sth = sth;
+  const double idet = 1.0 / det;
+  out.dth = (b1 * a22 - a12 * b2) * idet;
+  out.dnu3 = (a11 * b2 - a12 * b1) * idet;
+  out.c1 = c1; out.sig1 = sig1; out.sig2 = sig2; out.rs1 = rs1; out.rs2 = rs2;
   return 0;
 }
 
 // ---------------------------------------------------------------------------------------------
-// pass F: forward substitution (primal step), primal fraction-to-boundary, barrier slope
+// pass F: forward substitution (primal step), primal fraction-to-boundary, barrier slope and the
+// barrier sum at the current iterate
 // ---------------------------------------------------------------------------------------------
 #define ASC_FTB(a, val, dv) do { const double dv_ = (dv); if (dv_ < 0.0) a = fmin(a, -tau * (val) / dv_); } while (0)
+// same test with the reciprocal of the distance at hand: alpha <= tau / (-dv/val)
+#define ASC_FTBR(amax_inv, ival, dv) amax_inv = fmax(amax_inv, -(dv) * (ival))
 
-ASC_DEV void pass_forward(const Ctx &c, const Scal &s, double mu, double tau, double dth,
-                          double dnu3, double &apr, double &gd, double *dzK) {
-  const Der &d = c.d;
-  const int K = c.K;
-  const double hT = c.h * d.T, dt = hT * s.th, be = dt * d.alpha;
+struct InF {
+  double G[8], E[4], cc[7], F[7], ka[7], k0[3], id[6], a, m, u;
+};
+ASC_DEV void loadF(const Tile &t_, int k, InF &in) {
+  const gdbl *sp = t_.st(k);
+  ldn<8>(t_, sp, R_G, in.G);
+  ldn<4>(t_, sp, R_E, in.E);
+  ldn<7>(t_, sp, R_C, in.cc);
+  ldn<7>(t_, sp, R_F, in.F);
+  ldn<7>(t_, sp, R_KA, in.ka);
+  ldn<3>(t_, sp, R_K0, in.k0);
+  ldn<6>(t_, sp, R_ID, in.id);
+  in.a = ROW(sp, R_Z + IA);
+  in.m = ROW(sp, R_Z + IM);
+  in.u = ROW(sp, R_U);
+}
+
+ASC_PASS void pass_forward(const W &w, const Scal &s, double mu, double tau, double dth, double dnu3,
+                           double &apr, double &gd, double &slog, double *dzK) {
+  const Der &d = w.d;
+  const Tile t_(w);
+  const int K = uniform(w.K);
+  const double hT = w.h * d.T, dt = hT * s.th, be = dt * d.alpha;
   double dzp[7];
   ASC_UNROLL
   for (int i = 0; i < 7; i++) dzp[i] = 0.0;
-  for (int k = 0; k < K; k++) {
-    double G[8], E[4], xi[7], dz[7];
-    ASC_UNROLL
-    for (int i = 0; i < 8; i++) G[i] = c.at(c.L.sg, 8L * k + i);
-    ASC_UNROLL
-    for (int i = 0; i < 4; i++) E[i] = c.at(c.L.se, 4L * k + i);
-    double du = c.at(c.L.k0, 3L * k) + c.at(c.L.k0, 3L * k + 1) * dth + c.at(c.L.k0, 3L * k + 2) * dnu3;
+  double rmax = 0.0, gsum = 0.0, lsum = 0.0;   // max of -dx/dist over all bounds; barrier slope / mu; sum of logs
+  auto body = [&](InF &cur, int k) __attribute__((always_inline)) {
+    gdbl *sp = t_.st(k);
+    double xi[7], dz[7];
+    double du = cur.k0[0] + cur.k0[1] * dth + cur.k0[2] * dnu3;
     ASC_UNROLL
     for (int i = 0; i < 7; i++) {
-      xi[i] = dzp[i] - c.at(c.L.cc, 7L * k + i) + hT * c.at(c.L.sf, 7L * k + i) * dth;
-      du -= c.at(c.L.ka, 7L * k + i) * xi[i];
+      xi[i] = dzp[i] - cur.cc[i] + hT * cur.F[i] * dth;
+      du -= cur.ka[i] * xi[i];
     }
     xi[IW] += be * du;
-    solveA(G, E, dt, xi, dz);
-    ASC_UNROLL
-    for (int i = 0; i < 7; i++) { c.dz(k, i) = dz[i]; dzp[i] = dz[i]; }
-    c.du(k) = du;
-    const double a = c.z(k, IA), m = c.z(k, IM), u = c.u(k);
-    ASC_FTB(apr, a, dz[IA]); ASC_FTB(apr, d.aub - a, -dz[IA]);
-    ASC_FTB(apr, m, dz[IM]); ASC_FTB(apr, 1.0 - m, -dz[IM]);
-    ASC_FTB(apr, u + 1.0, du); ASC_FTB(apr, 1.0 - u, -du);
-    gd += dz[IA] * (-mu / a + mu / (d.aub - a)) + dz[IM] * (-mu / m + mu / (1.0 - m)) +
-          du * (-mu / (u + 1.0) + mu / (1.0 - u));
-  }
-  ASC_UNROLL
-  for (int i = 0; i < 7; i++) dzK[i] = dzp[i];
+    solveA(cur.G, cur.E, dt, xi, dz);
+    stn<7>(t_, sp, R_DZ, dz);
+    ROW(sp, R_DU) = du;
+    cpy<7>(dzp, dz);
+    const double *id = cur.id;
+    ASC_FTBR(rmax, id[0], dz[IA]); ASC_FTBR(rmax, id[1], -dz[IA]);
+    ASC_FTBR(rmax, id[2], dz[IM]); ASC_FTBR(rmax, id[3], -dz[IM]);
+    ASC_FTBR(rmax, id[4], du); ASC_FTBR(rmax, id[5], -du);
+    gsum += dz[IA] * (id[1] - id[0]) + dz[IM] * (id[3] - id[2]) + du * (id[5] - id[4]);
+    const double a = cur.a, m = cur.m, u = cur.u;
+    lsum += log((a * (d.aub - a)) * (m * (1.0 - m)) * ((u + 1.0) * (1.0 - u)));
+  };
+#define LD_(k_, buf_) loadF(t_, k_, buf_)
+  ASC_SWEEP_FORWARD(InF, LD_, body)
+#undef LD_
+  if (rmax * apr > tau) apr = tau / rmax;
+  gd += mu * gsum;
+  slog += lsum;
+  cpy<7>(dzK, dzp);
 }
 
 // ---------------------------------------------------------------------------------------------
 // pass A: adjoint substitution (multiplier step), bound-multiplier steps, dual fraction-to-boundary,
 // and c'(lambda + dlambda) for the curvature estimate
 // ---------------------------------------------------------------------------------------------
-ASC_DEV void pass_adjoint(const Ctx &c, const Scal &s, double mu, double dw, double tau, double dth,
-                          double dnu3, double sig1, double sig2, double &adu, double &cl) {
-  const Der &d = c.d;
-  const int K = c.K;
-  const double hT = c.h * d.T, dt = hT * s.th;
-  (void)hT;
-  double dln[7];
+struct InA {
+  double G[8], E[4], H[10], dz[7], l[7], zb[6], cc[7], id[6], du;
+};
+ASC_DEV void loadA(const Tile &t_, int k, InA &in) {
+  const gdbl *sp = t_.st(k);
+  ldn<8>(t_, sp, R_G, in.G);
+  ldn<4>(t_, sp, R_E, in.E);
+  ldn<10>(t_, sp, R_H, in.H);
+  ldn<7>(t_, sp, R_DZ, in.dz);
+  ldn<7>(t_, sp, R_L, in.l);
+  ldn<6>(t_, sp, R_ZB, in.zb);
+  ldn<7>(t_, sp, R_C, in.cc);
+  ldn<6>(t_, sp, R_ID, in.id);
+  in.du = ROW(sp, R_DU);
+}
+
+ASC_PASS void pass_adjoint(const W &w, const Scal &s, double mu, double dw, double tau, double dth,
+                           double dnu3, double sig1, double sig2, double rs1, double rs2, double &adu,
+                           double &cl) {
+  const Der &d = w.d;
+  const Tile t_(w);
+  const int K = uniform(w.K);
+  const double hT = w.h * d.T, dt = hT * s.th;
+  double dln[7], ln[7];
   ASC_UNROLL
-  for (int i = 0; i < 7; i++) dln[i] = 0.0;
-  for (int k = K - 1; k >= 0; k--) {
-    double G[8], E[4], H[10], dz[7], r[7], dl[7];
-    ASC_UNROLL
-    for (int i = 0; i < 8; i++) G[i] = c.at(c.L.sg, 8L * k + i);
-    ASC_UNROLL
-    for (int i = 0; i < 4; i++) E[i] = c.at(c.L.se, 4L * k + i);
-    ASC_UNROLL
-    for (int i = 0; i < 10; i++) H[i] = c.at(c.L.sh, 10L * k + i);
-    ASC_UNROLL
-    for (int i = 0; i < 7; i++) dz[i] = c.dz(k, i);
-    const double qa = c.at(c.L.qa, k), qm = c.at(c.L.qm, k);
+  for (int i = 0; i < 7; i++) { dln[i] = 0.0; ln[i] = 0.0; }
+  auto body = [&](InA &cur, int k) __attribute__((always_inline)) {
+    gdbl *sp = t_.st(k);
+    const double *H = cur.H, *dz = cur.dz, *id = cur.id;
+    const double du = cur.du;
+    const double qa = cur.zb[0] * id[0] + cur.zb[1] * id[1], qm = cur.zb[2] * id[2] + cur.zb[3] * id[3];
+    double fl[7], r[7], dl[7];
+    fzt_lambda(cur.G, cur.l, fl);
+    // r = -(rz + gt*dtheta) + dlambda_{k+1} - Q dz, with rz = l - dt*fl - l_{k+1} + barrier gradient
     ASC_UNROLL
     for (int i = 0; i < 7; i++)
-      r[i] = -c.at(c.L.rz, 7L * k + i) - c.at(c.L.gt, 7L * k + i) * dth + dln[i] - dw * dz[i];
+      r[i] = -(cur.l[i] - dt * fl[i] - ln[i]) + hT * fl[i] * dth + dln[i] - dw * dz[i];
+    r[IA] -= mu * (id[1] - id[0]);
+    r[IM] -= mu * (id[3] - id[2]);
     r[IX] -= H[0] * dz[IX] + H[1] * dz[IY] + H[2] * dz[IA] + H[3] * dz[IM];
     r[IY] -= H[1] * dz[IX] + H[4] * dz[IY] + H[5] * dz[IA] + H[6] * dz[IM];
     r[IA] -= H[2] * dz[IX] + H[5] * dz[IY] + (H[7] + qa) * dz[IA] + H[8] * dz[IM];
     r[IM] -= H[3] * dz[IX] + H[6] * dz[IY] + H[8] * dz[IA] + (H[9] + qm) * dz[IM];
     if (k == K - 1) {
       double zK[7], QT[28], qd[7];
-      ASC_UNROLL
-      for (int i = 0; i < 7; i++) zK[i] = c.z(k, i);
+      ldn<7>(t_, sp, R_Z, zK);
       const Terminal tm = terminal_eval(d, zK);
       ASC_UNROLL
       for (int i = 0; i < 28; i++) QT[i] = 0.0;
@@ -425,94 +537,81 @@ ASC_DEV void pass_adjoint(const Ctx &c, const Scal &s, double mu, double dw, dou
       symv(QT, dz, qd);
       ASC_UNROLL
       for (int i = 0; i < 7; i++) r[i] -= qd[i];
-      r[IX] -= tm.e3g[0] * dnu3; r[IY] -= tm.e3g[1] * dnu3;
-      r[IVX] -= tm.e3g[2] * dnu3; r[IVY] -= tm.e3g[3] * dnu3;
+      const double w1 = s.nu1 + sig1 * (tm.g1 - s.s1) + rs1, w2 = s.nu2 + sig2 * (tm.g2 - s.s2) + rs2;
+      r[IX] -= s.nu3 * tm.e3g[0] + w1 * tm.g1g[0] + tm.e3g[0] * dnu3;
+      r[IY] -= s.nu3 * tm.e3g[1] + w1 * tm.g1g[1] + tm.e3g[1] * dnu3;
+      r[IVX] -= s.nu3 * tm.e3g[2] + w2 * tm.g2g[0] + tm.e3g[2] * dnu3;
+      r[IVY] -= s.nu3 * tm.e3g[3] + w2 * tm.g2g[1] + tm.e3g[3] * dnu3;
     }
-    solveAT(G, E, dt, r, dl);
+    solveAT(cur.G, cur.E, dt, r, dl);
+    stn<7>(t_, sp, R_DL, dl);
     ASC_UNROLL
-    for (int i = 0; i < 7; i++) {
-      c.dlam(k, i) = dl[i];
-      dln[i] = dl[i];
-      cl += c.at(c.L.cc, 7L * k + i) * (c.lam(k, i) + dl[i]);
-    }
-    // bound multipliers of angle, mass, u
-    const double a = c.z(k, IA), m = c.z(k, IM), u = c.u(k), du = c.du(k);
-    const double lo[3] = {a, m, u + 1.0}, up[3] = {d.aub - a, 1.0 - m, 1.0 - u};
+    for (int i = 0; i < 7; i++) cl += cur.cc[i] * (cur.l[i] + dl[i]);
+    // bound multipliers: dz_L = mu/d - z_L - z_L/d*dx,  dz_U = mu/d - z_U + z_U/d*dx
     const double dx[3] = {dz[IA], dz[IM], du};
+    double dzb[6];
     ASC_UNROLL
     for (int b = 0; b < 3; b++) {
-      const double zl = c.zb(k, 2 * b), zu = c.zb(k, 2 * b + 1);
-      const double dzl = mu / lo[b] - zl - zl / lo[b] * dx[b];
-      const double dzu = mu / up[b] - zu + zu / up[b] * dx[b];
-      c.dzb(k, 2 * b) = dzl;
-      c.dzb(k, 2 * b + 1) = dzu;
-      ASC_FTB(adu, zl, dzl);
-      ASC_FTB(adu, zu, dzu);
+      const double zl = cur.zb[2 * b], zu = cur.zb[2 * b + 1];
+      dzb[2 * b] = id[2 * b] * (mu - zl * dx[b]) - zl;
+      dzb[2 * b + 1] = id[2 * b + 1] * (mu + zu * dx[b]) - zu;
+      ASC_FTB(adu, zl, dzb[2 * b]);
+      ASC_FTB(adu, zu, dzb[2 * b + 1]);
     }
-  }
+    stn<6>(t_, sp, R_DZB, dzb);
+    cpy<7>(dln, dl);
+    cpy<7>(ln, cur.l);
+  };
+#define LD_(k_, buf_) loadA(t_, k_, buf_)
+  ASC_SWEEP_BACKWARD(InA, LD_, body)
+#undef LD_
 }
 
 // ---------------------------------------------------------------------------------------------
 // pass T: l1 merit function at the trial point iterate + alpha*step
 // ---------------------------------------------------------------------------------------------
-ASC_DEV double pass_trial(const Ctx &c, const Scal &s, const Scal &ds, double alpha, double mu,
-                          double nu_pen) {
-  const Der &d = c.d;
-  const int K = c.K;
+struct InT {
+  double z[7], dz[7], u, du;
+};
+ASC_DEV void loadT(const Tile &t_, int k, InT &in) {
+  const gdbl *sp = t_.st(k);
+  ldn<7>(t_, sp, R_Z, in.z);
+  ldn<7>(t_, sp, R_DZ, in.dz);
+  in.u = ROW(sp, R_U);
+  in.du = ROW(sp, R_DU);
+}
+
+ASC_PASS double pass_trial(const W &w, const Scal &s, const Scal &ds, double alpha, double mu, double nu_pen) {
+  const Der &d = w.d;
+  const Tile t_(w);
+  const int K = uniform(w.K);
   const double th = s.th + alpha * ds.th, s1 = s.s1 + alpha * ds.s1, s2 = s.s2 + alpha * ds.s2;
-  const double dt = c.h * d.T * th;
-  double sl = log(th - d.tlb) + log(d.tub - th) + log(s1) + log(s2);
+  const double dt = w.h * d.T * th;
+  double sl = log(((th - d.tlb) * (d.tub - th)) * (s1 * s2));
   double c1 = 0.0, zp[7], z[7];
   ASC_UNROLL
-  for (int i = 0; i < 7; i++) zp[i] = 0.0;
-  for (int k = 0; k < K; k++) {
+  for (int i = 0; i < 7; i++) { zp[i] = 0.0; z[i] = 0.0; }
+  auto body = [&](InT &cur, int k) __attribute__((always_inline)) {
+    (void)k;
     double F[7], ax, ay;
     ASC_UNROLL
-    for (int i = 0; i < 7; i++) z[i] = c.z(k, i) + alpha * c.dz(k, i);
-    const double u = c.u(k) + alpha * c.du(k);
+    for (int i = 0; i < 7; i++) z[i] = cur.z[i] + alpha * cur.dz[i];
+    const double u = cur.u + alpha * cur.du;
     accel<0>(d, z[IX], z[IY], z[IA], z[IM], 0.0, 0.0, ax, ay, nullptr, nullptr);
     rhs_f(d, z, u, ax, ay, F);
     ASC_UNROLL
     for (int i = 0; i < 7; i++) { c1 += fabs(z[i] - zp[i] - dt * F[i]); zp[i] = z[i]; }
-    sl += log(z[IA]) + log(d.aub - z[IA]) + log(z[IM]) + log(1.0 - z[IM]) + log(u + 1.0) + log(1.0 - u);
-  }
+    // a negative factor (trial point outside a bound) gives NaN or a wrong sign pair; the fraction-to-
+    // boundary rule keeps every factor positive, and a NaN merit value is rejected by the line search
+    const double pa = z[IA] * (d.aub - z[IA]), pm = z[IM] * (1.0 - z[IM]), pu = (u + 1.0) * (1.0 - u);
+    sl += (pa > 0.0 && pm > 0.0 && pu > 0.0) ? log(pa * pm * pu) : NAN;
+  };
+#define LD_(k_, buf_) loadT(t_, k_, buf_)
+  ASC_SWEEP_FORWARD(InT, LD_, body)
+#undef LD_
   const Terminal tm = terminal_eval(d, z);
   c1 += fabs(tm.e3) + fabs(tm.g1 - s1) + fabs(tm.g2 - s2);
   return th - mu * sl + nu_pen * c1;
-}
-
-ASC_DEV double barrier_now(const Ctx &c, const Scal &s, double mu) {
-  const Der &d = c.d;
-  double sl = log(s.th - d.tlb) + log(d.tub - s.th) + log(s.s1) + log(s.s2);
-  for (int k = 0; k < c.K; k++) {
-    const double a = c.z(k, IA), m = c.z(k, IM), u = c.u(k);
-    sl += log(a) + log(d.aub - a) + log(m) + log(1.0 - m) + log(u + 1.0) + log(1.0 - u);
-  }
-  return s.th - mu * sl;
-}
-
-// ---------------------------------------------------------------------------------------------
-// pass U: accept the step
-// ---------------------------------------------------------------------------------------------
-ASC_DEV double clipz(double zv, double dist, double mu) {
-  return fmin(fmax(zv, mu / (1e10 * dist)), 1e10 * mu / dist);
-}
-
-ASC_DEV void pass_update(const Ctx &c, double alpha, double adu, double mu) {
-  const Der &d = c.d;
-  const int K = c.K;
-  for (int k = 0; k < K; k++) {
-    ASC_UNROLL
-    for (int i = 0; i < 7; i++) {
-      c.z(k, i) += alpha * c.dz(k, i);
-      c.lam(k, i) += alpha * c.dlam(k, i);
-    }
-    c.u(k) += alpha * c.du(k);
-    const double a = c.z(k, IA), m = c.z(k, IM), u = c.u(k);
-    const double dist[6] = {a, d.aub - a, m, 1.0 - m, u + 1.0, 1.0 - u};
-    ASC_UNROLL
-    for (int b = 0; b < 6; b++) c.zb(k, b) = clipz(c.zb(k, b) + adu * c.dzb(k, b), dist[b], mu);
-  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -525,45 +624,48 @@ ASC_DEV double push_in(double v, double lb, double ub) {
   return fmin(fmax(v, lb + pl), ub - pu);
 }
 
-// straight-line states toward a tangential insertion point, u = 0 (cold start)
-ASC_DEV void cold_guess(const Ctx &c, Scal &s) {
-  const Der &d = c.d;
-  const int K = c.K;
-  const double tf0 = 0.9, dr = 0.166, aend = 0.5, vp = sqrt(d.vp2), dt = c.h * d.T * tf0;
+// cold start: straight-line states toward a tangential insertion point, u = 0
+ASC_DEV void cold_guess(const W &w, Scal &s) {
+  const Der &d = w.d;
+  const Tile t_(w);
+  const int K = uniform(w.K);
+  const double tf0 = 0.9, dr = 0.166, aend = 0.5, vp = sqrt(d.vp2), dt = w.h * d.T * tf0;
   const double sdr = sin(dr), cdr = cos(dr);
   const double xf = -d.rhof * sdr, yf = d.rhof * cdr - d.rho0;
   for (int k = 0; k < K; k++) {
     const double fr = (double)(k + 1) / K;
-    c.z(k, IX) = fr * xf; c.z(k, IY) = fr * yf;
-    c.z(k, IVX) = -fr * vp * cdr; c.z(k, IVY) = -fr * vp * sdr;
-    c.z(k, IA) = fr * aend; c.z(k, IW) = aend / (K * dt); c.z(k, IM) = d.mrate * dt * (k + 1);
-    c.u(k) = 0.0;
+    gdbl *sp = t_.st(k);
+    const double z[7] = {fr * xf, fr * yf, -fr * vp * cdr, -fr * vp * sdr, fr * aend, aend / (K * dt),
+                         d.mrate * dt * (k + 1)};
+    stn<7>(t_, sp, R_Z, z);
+    ROW(sp, R_U) = 0.0;
   }
   s.th = tf0;
 }
 
 // interior point + multipliers. mode 0/1: primal only (multipliers reset); 2: keep multipliers
-ASC_DEV void init_point(const Ctx &c, Scal &s, int mode) {
-  const Der &d = c.d;
-  const int K = c.K;
+ASC_DEV void init_point(const W &w, Scal &s, int mode) {
+  const Der &d = w.d;
+  const Tile t_(w);
+  const int K = uniform(w.K);
   for (int k = 0; k < K; k++) {
-    c.z(k, IA) = push_in(c.z(k, IA), 0.0, d.aub);
-    c.z(k, IM) = push_in(c.z(k, IM), 0.0, 1.0);
-    c.u(k) = push_in(c.u(k), -1.0, 1.0);
+    gdbl *sp = t_.st(k);
+    ROW(sp, R_Z + IA) = push_in(ROW(sp, R_Z + IA), 0.0, d.aub);
+    ROW(sp, R_Z + IM) = push_in(ROW(sp, R_Z + IM), 0.0, 1.0);
+    ROW(sp, R_U) = push_in(ROW(sp, R_U), -1.0, 1.0);
     if (mode != 2) {
       ASC_UNROLL
-      for (int b = 0; b < 6; b++) c.zb(k, b) = 1.0;
+      for (int b = 0; b < 6; b++) ROW(sp, R_ZB + b) = 1.0;
       ASC_UNROLL
-      for (int i = 0; i < 7; i++) c.lam(k, i) = 0.0;
+      for (int i = 0; i < 7; i++) ROW(sp, R_L + i) = 0.0;
     } else {
       ASC_UNROLL
-      for (int b = 0; b < 6; b++) c.zb(k, b) = fmax(c.zb(k, b), 1e-12);
+      for (int b = 0; b < 6; b++) ROW(sp, R_ZB + b) = fmax(ROW(sp, R_ZB + b), 1e-12);
     }
   }
   s.th = push_in(s.th, d.tlb, d.tub);
   double zK[7];
-  ASC_UNROLL
-  for (int i = 0; i < 7; i++) zK[i] = c.z(K - 1, i);
+  ldn<7>(t_, t_.st(K - 1), R_Z, zK);
   const Terminal tm = terminal_eval(d, zK);
   if (mode != 2) {
     s.s1 = fmax(tm.g1, 1e-2); s.s2 = fmax(tm.g2, 1e-2);
@@ -577,20 +679,19 @@ ASC_DEV void init_point(const Ctx &c, Scal &s, int mode) {
 }
 
 // Newton step at the current iterate: passes B, F, A.  Returns 0 / 1 (wrong inertia).
-struct StepInfo { double apr, adu, gd, cl, c1; };
+struct StepInfo { double apr, adu, gd, cl, c1, slog; };
 
-ASC_DEV int newton_step(const Ctx &c, const Scal &s, double mu, double dw, Scal &ds, StepInfo &si) {
+ASC_DEV int newton_step(const W &w, const Scal &s, double mu, double dw, Scal &ds, StepInfo &si) {
   BorderOut bo;
-  if (pass_backward(c, s, mu, dw, bo)) return 1;
-  const Der &d = c.d;
+  if (pass_backward(w, s, mu, dw, bo)) return 1;
+  const Der &d = w.d;
   const double tau = fmax(0.99, 1.0 - mu);
-  double apr = 1.0, adu = 1.0, gd = 0.0, cl = 0.0, dzK[7];
-  pass_forward(c, s, mu, tau, bo.dth, bo.dnu3, apr, gd, dzK);
-  pass_adjoint(c, s, mu, dw, tau, bo.dth, bo.dnu3, bo.sig1, bo.sig2, adu, cl);
-  // slacks, their multipliers, tf bounds
+  double apr = 1.0, adu = 1.0, gd = 0.0, cl = 0.0, slog = 0.0, dzK[7];
+  pass_forward(w, s, mu, tau, bo.dth, bo.dnu3, apr, gd, slog, dzK);
+  pass_adjoint(w, s, mu, dw, tau, bo.dth, bo.dnu3, bo.sig1, bo.sig2, bo.rs1, bo.rs2, adu, cl);
   double zK[7];
-  ASC_UNROLL
-  for (int i = 0; i < 7; i++) zK[i] = c.z(c.K - 1, i);
+  const Tile t_(w);
+  ldn<7>(t_, t_.st(w.K - 1), R_Z, zK);
   const Terminal tm = terminal_eval(d, zK);
   ds.th = bo.dth; ds.nu3 = bo.dnu3;
   ds.s1 = (tm.g1 - s.s1) + tm.g1g[0] * dzK[IX] + tm.g1g[1] * dzK[IY];
@@ -608,45 +709,98 @@ ASC_DEV int newton_step(const Ctx &c, const Scal &s, double mu, double dw, Scal 
   ASC_FTB(adu, s.zs1, ds.zs1); ASC_FTB(adu, s.zs2, ds.zs2);
   gd += ds.th * (1.0 - mu / dl + mu / dU) - mu * ds.s1 / s.s1 - mu * ds.s2 / s.s2;
   cl += tm.e3 * (s.nu3 + ds.nu3) + (tm.g1 - s.s1) * (s.nu1 + ds.nu1) + (tm.g2 - s.s2) * (s.nu2 + ds.nu2);
-  si.apr = apr; si.adu = adu; si.gd = gd; si.cl = cl; si.c1 = bo.c1;
+  slog += log((dl * dU) * (s.s1 * s.s2));
+  si.apr = apr; si.adu = adu; si.gd = gd; si.cl = cl; si.c1 = bo.c1; si.slog = slog;
   return 0;
 }
 
-ASC_DEV Ctx make_ctx(double *ws, const Layout &L, long p, const ascent_params *params) {
-  Ctx c;
-  c.ws = ws + p;
-  c.B = L.B;
-  c.K = L.K;
-  c.h = 1.0 / L.K;
-  c.L = L;
-  c.d = derive(params[p]);
-  return c;
+ASC_DEV W make_w(double *ws, int K, const ascent_params &prm) {
+  W w;
+  w.tile = (gdbl *)ws + (size_t)blockIdx.x * tile_doubles(K);
+  w.K = K;
+  w.h = 1.0 / K;
+  w.d = derive(prm);
+  return w;
+}
+
+// external blob rows ([row][batch], include/ascent.h) <-> step records
+ASC_DEV void blob_to_tile(const W &w, const double *blob, long batch, long p, int r_z, int r_u, int r_l,
+                          int r_zb, Scal &s) {
+  const Tile t_(w);
+  const int K = uniform(w.K);
+  for (int k = 0; k < K; k++) {
+    gdbl *sp = t_.st(k);
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) {
+      ROW(sp, r_z + i) = blob[(7L * k + i) * batch + p];
+      ROW(sp, r_l + i) = blob[(8L * K + 7L * k + i) * batch + p];
+    }
+    ROW(sp, r_u) = blob[(7L * K + k) * batch + p];
+    ASC_UNROLL
+    for (int b = 0; b < 6; b++) ROW(sp, r_zb + b) = blob[(15L * K + 6L * k + b) * batch + p];
+  }
+  const double *sc = blob + (21L * K) * batch + p;
+  s.th = sc[S_TH * batch]; s.zlt = sc[S_ZLT * batch]; s.zut = sc[S_ZUT * batch];
+  s.s1 = sc[S_S1 * batch]; s.s2 = sc[S_S2 * batch]; s.zs1 = sc[S_ZS1 * batch]; s.zs2 = sc[S_ZS2 * batch];
+  s.nu3 = sc[S_NU3 * batch]; s.nu1 = sc[S_NU1 * batch]; s.nu2 = sc[S_NU2 * batch];
+}
+
+ASC_DEV void tile_to_blob(const W &w, double *blob, long batch, long p, int r_z, int r_u, int r_l, int r_zb,
+                          const Scal &s) {
+  const Tile t_(w);
+  const int K = uniform(w.K);
+  for (int k = 0; k < K; k++) {
+    const gdbl *sp = t_.st(k);
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) {
+      blob[(7L * k + i) * batch + p] = ROW(sp, r_z + i);
+      blob[(8L * K + 7L * k + i) * batch + p] = ROW(sp, r_l + i);
+    }
+    blob[(7L * K + k) * batch + p] = ROW(sp, r_u);
+    ASC_UNROLL
+    for (int b = 0; b < 6; b++) blob[(15L * K + 6L * k + b) * batch + p] = ROW(sp, r_zb + b);
+  }
+  double *sc = blob + (21L * K) * batch + p;
+  sc[S_TH * batch] = s.th; sc[S_ZLT * batch] = s.zlt; sc[S_ZUT * batch] = s.zut;
+  sc[S_S1 * batch] = s.s1; sc[S_S2 * batch] = s.s2; sc[S_ZS1 * batch] = s.zs1; sc[S_ZS2 * batch] = s.zs2;
+  sc[S_NU3 * batch] = s.nu3; sc[S_NU1 * batch] = s.nu1; sc[S_NU2 * batch] = s.nu2;
 }
 
 // ---------------------------------------------------------------------------------------------
 // kernels
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_solve(const ascent_params *params, long batch, Layout L,
-                                              double *ws, const double *guess, int warm, int max_iter,
-                                              double tol, double mu_init, double *traj, double *tf_out,
-                                              int *status_out, int *iters_out, double *blob_out) {
-  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= batch) return;
-  const Ctx c = make_ctx(ws, L, p, params);
-  const int K = c.K;
-  const long rows = 21L * K + NSC;
+#ifdef ASCENT_PROFILE   // diagnostic build only (scripts/pass_profile.py): shader cycles per pass
+__device__ unsigned long long g_prof[8];
+#define PROF_T0 long long t0_ = clock64();
+#define PROF_ADD(i) do { long long t1_ = clock64(); prof[i] += t1_ - t0_; t0_ = t1_; } while (0)
+#else
+#define PROF_T0
+#define PROF_ADD(i) do { } while (0)
+#endif
+
+__global__ __launch_bounds__(WAVE) void k_solve(const ascent_params *params, long batch, int lpt, int K, double *ws,
+                                                const double *guess, int warm, int max_iter, double tol,
+                                                double mu_init, double *traj, double *tf_out, int *status_out,
+                                                int *iters_out, double *blob_out) {
+  const long p = (long)blockIdx.x * lpt + threadIdx.x;
+  if ((int)threadIdx.x >= lpt || p >= batch) return;
+  const W w = make_w(ws, K, params[p]);
   Scal s;
   if (warm) {
-    for (long r = 0; r < rows; r++) c.at(L.it, r) = guess[r * batch + p];
-    s = load_scal(c, L.it);
+    blob_to_tile(w, guess, batch, p, R_Z, R_U, R_L, R_ZB, s);
   } else {
-    cold_guess(c, s);
+    cold_guess(w, s);
   }
-  init_point(c, s, warm);
+  init_point(w, s, warm);
   double mu = mu_init, nu_pen = 1.0, dw_last = 0.0;
   int status = ASCENT_MAX_ITER, iters = 0;
+#ifdef ASCENT_PROFILE
+  long long prof[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+  PROF_T0
+  ErrParts e = pass_update_error<false>(w, s, 0.0, 0.0, mu);
+  PROF_ADD(0);
   for (int iter = 0; iter < max_iter; iter++) {
-    const ErrParts e = pass_error(c, s);
     if (e.err(0.0) <= tol) { status = ASCENT_CONVERGED; break; }
     while (mu > tol * 0.1 && e.err(mu) <= 10.0 * mu) {
       mu = fmax(tol * 0.1, fmin(0.2 * mu, mu * sqrt(mu)));
@@ -656,50 +810,61 @@ __global__ __launch_bounds__(64) void k_solve(const ascent_params *params, long 
     Scal ds;
     StepInfo si;
     bool fail = false;
-    while (newton_step(c, s, mu, dw, ds, si)) {
+    while (newton_step(w, s, mu, dw, ds, si)) {
       dw = dw == 0.0 ? fmax(1e-4, dw_last / 3.0) : dw * 8.0;
       if (dw > 1e10) { fail = true; break; }
     }
     if (fail) { status = ASCENT_REGULARISATION_FAILED; break; }
     dw_last = dw;
+    PROF_ADD(1);
     const double curv = -si.gd + si.cl;
     if (si.c1 > 0.0) {
       const double need = (si.gd + 0.5 * fmax(curv, 0.0)) / (0.9 * si.c1);
       if (nu_pen < need) nu_pen = need + 1.0;
     }
     const double Dm = si.gd - nu_pen * si.c1;
-    const double phi0 = barrier_now(c, s, mu) + nu_pen * si.c1;
+    const double phi0 = s.th - mu * si.slog + nu_pen * si.c1;
     double alpha = si.apr;
     bool ok = false;
     for (int ls = 0; ls < 40; ls++) {
-      const double phit = pass_trial(c, s, ds, alpha, mu, nu_pen);
+      const double phit = pass_trial(w, s, ds, alpha, mu, nu_pen);
       if (isfinite(phit) && phit <= phi0 + 1e-8 * alpha * Dm + 2.220446049250313e-15 * fabs(phi0)) { ok = true; break; }
       alpha *= 0.5;
     }
     if (!ok) { status = ASCENT_LINESEARCH_FAILED; break; }
-    pass_update(c, alpha, si.adu, mu);
+    PROF_ADD(3);
     s.th += alpha * ds.th; s.s1 += alpha * ds.s1; s.s2 += alpha * ds.s2;
     s.nu3 += alpha * ds.nu3; s.nu1 += alpha * ds.nu1; s.nu2 += alpha * ds.nu2;
-    s.zlt = clipz(s.zlt + si.adu * ds.zlt, s.th - c.d.tlb, mu);
-    s.zut = clipz(s.zut + si.adu * ds.zut, c.d.tub - s.th, mu);
+    s.zlt = clipz(s.zlt + si.adu * ds.zlt, s.th - w.d.tlb, mu);
+    s.zut = clipz(s.zut + si.adu * ds.zut, w.d.tub - s.th, mu);
     s.zs1 = clipz(s.zs1 + si.adu * ds.zs1, s.s1, mu);
     s.zs2 = clipz(s.zs2 + si.adu * ds.zs2, s.s2, mu);
+    e = pass_update_error<true>(w, s, alpha, si.adu, mu);
     iters = iter + 1;
+    PROF_ADD(4);
   }
-  store_scal(c, L.it, s);
+  if (status == ASCENT_MAX_ITER && e.err(0.0) <= tol) status = ASCENT_CONVERGED;
+#ifdef ASCENT_PROFILE
+  if (threadIdx.x == 0)
+    for (int i = 0; i < 8; i++) atomicAdd(&g_prof[i], (unsigned long long)prof[i]);
+#endif
   tf_out[p] = s.th;
   status_out[p] = status;
   iters_out[p] = iters;
-  if (blob_out)
-    for (long r = 0; r < rows; r++) blob_out[r * batch + p] = c.at(L.it, r);
+  if (blob_out) tile_to_blob(w, blob_out, batch, p, R_Z, R_U, R_L, R_ZB, s);
   if (traj) {
+    const Tile t_(w);
     const int nt = K + 1;
     for (int k = 0; k < nt; k++) {
       double z[7], u = 0.0, ax, ay;
-      ASC_UNROLL
-      for (int i = 0; i < 7; i++) z[i] = k ? c.z(k - 1, i) : 0.0;
-      if (k) u = c.u(k - 1);
-      accel<0>(c.d, z[IX], z[IY], z[IA], z[IM], 0.0, 0.0, ax, ay, nullptr, nullptr);
+      if (k) {
+        ldn<7>(t_, t_.st(k - 1), R_Z, z);
+        u = ROW(t_.st(k - 1), R_U);
+      } else {
+        ASC_UNROLL
+        for (int i = 0; i < 7; i++) z[i] = 0.0;
+      }
+      accel<0>(w.d, z[IX], z[IY], z[IA], z[IM], 0.0, 0.0, ax, ay, nullptr, nullptr);
       const double v[10] = {z[IX], z[IY], z[IVX], z[IVY], ax, ay, z[IA], z[IW], u, z[IM]};
       ASC_UNROLL
       for (int f = 0; f < 10; f++) traj[((long)f * nt + k) * batch + p] = v[f];
@@ -735,23 +900,18 @@ __global__ __launch_bounds__(256) void k_eval_nodes(const ascent_params *params,
   for (int i = 0; i < 10; i++) hess[(10L * k + i) * batch + p] = H[i];
 }
 
-__global__ __launch_bounds__(64) void k_kkt_step(const ascent_params *params, long batch, Layout L,
-                                                 double *ws, const double *it, const double *mu,
-                                                 const double *dw, double *step, int *inertia) {
-  const long p = (long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (p >= batch) return;
-  const Ctx c = make_ctx(ws, L, p, params);
-  const long rows = 21L * c.K + NSC;
-  for (long r = 0; r < rows; r++) c.at(L.it, r) = it[r * batch + p];
-  const Scal s = load_scal(c, L.it);
-  Scal ds;
+__global__ __launch_bounds__(WAVE) void k_kkt_step(const ascent_params *params, long batch, int lpt, int K, double *ws,
+                                                   const double *it, const double *mu, const double *dw,
+                                                   double *step, int *inertia) {
+  const long p = (long)blockIdx.x * lpt + threadIdx.x;
+  if ((int)threadIdx.x >= lpt || p >= batch) return;
+  const W w = make_w(ws, K, params[p]);
+  Scal s, ds;
+  blob_to_tile(w, it, batch, p, R_Z, R_U, R_L, R_ZB, s);
   StepInfo si;
-  const int rc = newton_step(c, s, mu[p], dw[p], ds, si);
+  const int rc = newton_step(w, s, mu[p], dw[p], ds, si);
   inertia[p] = rc;
-  if (rc == 0) {
-    store_scal(c, L.st, ds);
-    for (long r = 0; r < rows; r++) step[r * batch + p] = c.at(L.st, r);
-  }
+  if (rc == 0) tile_to_blob(w, step, batch, p, R_DZ, R_DU, R_DL, R_DZB, ds);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -774,6 +934,20 @@ struct DeviceWs {
 constexpr int MAX_DEV = 64;
 DeviceWs g_ws[MAX_DEV];
 std::mutex g_mu[MAX_DEV];
+
+// NLPs per wavefront (tile). 64 fills every lane; smaller values spread a small batch over more
+// wavefronts (and so more SIMDs) at the price of idle lanes.  Chosen per launch by lanes_per_tile().
+int lanes_per_tile(int64_t batch) {
+  const char *e = getenv("ASCENT_LANES_PER_WAVE");
+  if (e) { const int v = atoi(e); if (v == 64 || v == 32 || v == 16 || v == 8) return v; }
+  (void)batch;
+  return WAVE;
+}
+
+size_t ws_bytes(int K, int64_t batch, int lpt) {
+  const size_t tiles = (size_t)((batch + lpt - 1) / lpt);
+  return tiles * tile_doubles(K) * sizeof(double);
+}
 
 int ensure_ws(int dev, size_t bytes) {
   DeviceWs &w = g_ws[dev];
@@ -815,7 +989,16 @@ struct DevBuf {  // device staging buffer for host-pointer calls
 
 extern "C" {
 
-int ascent_version(void) { return 100; }
+#ifdef ASCENT_PROFILE
+int ascent_debug_profile(unsigned long long *out8, int reset) {
+  unsigned long long z[8] = {0};
+  if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_prof), sizeof z) != hipSuccess) return -1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_prof), z, sizeof z) != hipSuccess) return -1;
+  return 0;
+}
+#endif
+
+int ascent_version(void) { return 101; }
 
 int ascent_device_count(void) {
   int n = 0;
@@ -857,9 +1040,9 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
   HIPCHK(hipSetDevice(device_id));
   hipStream_t stream = (hipStream_t)stream_;
   const int K = o->n_nodes - 1, nt = o->n_nodes;
-  const long rows = 21L * K + NSC;
-  const Layout L = make_layout(K, (long)batch);
-  rc = ensure_ws(device_id, (size_t)L.total * (size_t)batch * sizeof(double));
+  const size_t rows = 21 * (size_t)K + NSC;
+  const int lpt = lanes_per_tile(batch);
+  rc = ensure_ws(device_id, ws_bytes(K, batch, lpt));
   if (rc) return rc;
   DeviceWs &w = g_ws[device_id];
   const double mu0 = o->mu_init > 0 ? o->mu_init : (o->warm_start ? 1e-4 : 0.1);
@@ -886,9 +1069,9 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
     HIPCHK(bstatus.alloc(batch)); dstatus = bstatus.d;
     HIPCHK(biters.alloc(batch)); diters = biters.d;
   }
-  const unsigned grid = (unsigned)((batch + 63) / 64);
+  const unsigned grid = (unsigned)((batch + lpt - 1) / lpt);
   HIPCHK(hipEventRecord(w.ev0, stream));
-  hipLaunchKernelGGL(k_solve, dim3(grid), dim3(64), 0, stream, dp, (long)batch, L, w.ws, dguess,
+  hipLaunchKernelGGL(k_solve, dim3(grid), dim3(WAVE), 0, stream, dp, (long)batch, lpt, K, w.ws, dguess,
                      (int)o->warm_start, (int)o->max_iter, o->tol, mu0, dtraj, dtf, dstatus, diters, dblob);
   HIPCHK(hipGetLastError());
   HIPCHK(hipEventRecord(w.ev1, stream));
@@ -912,19 +1095,19 @@ int ascent_eval_nodes(const ascent_params *p, int64_t batch, const ascent_opts *
   std::lock_guard<std::mutex> lock(g_mu[device_id]);
   HIPCHK(hipSetDevice(device_id));
   const int K = o->n_nodes - 1;
-  const long rows = 21L * K + NSC;
+  const size_t rows = 21 * (size_t)K + NSC;
   DevBuf<ascent_params> bp;
   DevBuf<double> bit, bd, bj, bh;
   HIPCHK(bp.alloc(batch)); HIPCHK(bit.alloc(rows * batch));
-  HIPCHK(bd.alloc(7L * K * batch)); HIPCHK(bj.alloc(8L * K * batch)); HIPCHK(bh.alloc(10L * K * batch));
+  HIPCHK(bd.alloc((size_t)7 * K * batch)); HIPCHK(bj.alloc((size_t)8 * K * batch)); HIPCHK(bh.alloc((size_t)10 * K * batch));
   HIPCHK(hipMemcpy(bp.d, p, batch * sizeof(ascent_params), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(bit.d, iterate, rows * batch * sizeof(double), hipMemcpyHostToDevice));
   hipLaunchKernelGGL(k_eval_nodes, dim3((unsigned)((batch + 255) / 256), K), dim3(256), 0, 0, bp.d, (long)batch, K,
                      bit.d, bd.d, bj.d, bh.d);
   HIPCHK(hipGetLastError());
-  HIPCHK(hipMemcpy(defects, bd.d, 7L * K * batch * sizeof(double), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(jac_blocks, bj.d, 8L * K * batch * sizeof(double), hipMemcpyDeviceToHost));
-  HIPCHK(hipMemcpy(hess_blocks, bh.d, 10L * K * batch * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(defects, bd.d, (size_t)7 * K * batch * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(jac_blocks, bj.d, (size_t)8 * K * batch * sizeof(double), hipMemcpyDeviceToHost));
+  HIPCHK(hipMemcpy(hess_blocks, bh.d, (size_t)10 * K * batch * sizeof(double), hipMemcpyDeviceToHost));
   return ASCENT_OK;
 }
 
@@ -936,9 +1119,9 @@ int ascent_kkt_step(const ascent_params *p, int64_t batch, const ascent_opts *o,
   std::lock_guard<std::mutex> lock(g_mu[device_id]);
   HIPCHK(hipSetDevice(device_id));
   const int K = o->n_nodes - 1;
-  const long rows = 21L * K + NSC;
-  const Layout L = make_layout(K, (long)batch);
-  rc = ensure_ws(device_id, (size_t)L.total * (size_t)batch * sizeof(double));
+  const size_t rows = 21 * (size_t)K + NSC;
+  const int lpt = lanes_per_tile(batch);
+  rc = ensure_ws(device_id, ws_bytes(K, batch, lpt));
   if (rc) return rc;
   DevBuf<ascent_params> bp;
   DevBuf<double> bit, bmu, bdw, bst;
@@ -950,7 +1133,7 @@ int ascent_kkt_step(const ascent_params *p, int64_t batch, const ascent_opts *o,
   HIPCHK(hipMemcpy(bmu.d, mu, batch * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(bdw.d, delta_w, batch * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemset(bst.d, 0, rows * batch * sizeof(double)));
-  hipLaunchKernelGGL(k_kkt_step, dim3((unsigned)((batch + 63) / 64)), dim3(64), 0, 0, bp.d, (long)batch, L,
+  hipLaunchKernelGGL(k_kkt_step, dim3((unsigned)((batch + lpt - 1) / lpt)), dim3(WAVE), 0, 0, bp.d, (long)batch, lpt, K,
                      g_ws[device_id].ws, bit.d, bmu.d, bdw.d, bst.d, bin.d);
   HIPCHK(hipGetLastError());
   HIPCHK(hipMemcpy(step, bst.d, rows * batch * sizeof(double), hipMemcpyDeviceToHost));
