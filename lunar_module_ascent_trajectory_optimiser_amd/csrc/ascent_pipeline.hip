@@ -1,0 +1,897 @@
+// Split pipeline of the batched ascent NLP solver for small and medium batches (gfx950).
+//
+// The fused kernel (ascent_solver.hip) gives every NLP one lane and sweeps the 199 collocation steps
+// serially for everything; at batch 4096 that occupies 64 of the chip's 1024 SIMDs.  Only the three
+// recurrences of a Newton step are inherently serial in time: the Riccati factorisation, the forward
+// substitution and the adjoint substitution.  Everything else -- the trial point x + alpha*dx, the
+// dynamics defects and their Jacobian/Hessian blocks at every collocation node (Launch_Optimiser.py:
+// 114-136), the merit function and the KKT error -- has no recurrence.  This file therefore runs one
+// interior-point iteration as
+//     q_trial_eval   grid (tiles x step-chunks): trial point, node evaluation, merit + error partials
+//     q_decide_factor one wavefront per tile: line-search / convergence / barrier decisions per lane,
+//                     then the backward factorisation of the bordered block-tridiagonal KKT system
+//     q_forward      one wavefront per tile: primal step, adjoint right-hand side, bound-multiplier
+//                     steps, fraction-to-boundary
+//     q_adjoint      one wavefront per tile: multiplier step, step-size/merit bookkeeping
+// driven by a host loop that reads three counters per iteration.  Lanes carry a small state machine
+// (trial / factor / factored / done), so a rejected line-search trial or a wrong-inertia
+// factorisation re-runs only the lanes concerned.  The arithmetic per lane is the same as in the
+// fused kernel; lanes of one tile still never talk to each other.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+#include "ascent.h"
+#include "ascent_device.hpp"
+#include "ascent_tile.hpp"
+#include "ascent_pipeline.hpp"
+
+using namespace ascent;
+
+namespace {
+
+// ---- rows of one step record -----------------------------------------------------------------
+constexpr int Q_IT = 0;                 // two iterate buffers of 21 rows: z[7] u lambda[7] zb[6]
+constexpr int Q_ST = 42;                // step: dz[7] du dlambda[7] dzb[6]
+constexpr int O_Z = 0, O_U = 7, O_L = 8, O_ZB = 15;
+constexpr int Q_G = 63, Q_E = 71, Q_H = 75, Q_F = 85, Q_C = 92, Q_RZ = 99, Q_GT = 106, Q_SC = 113;
+constexpr int Q_KA = 120, Q_K0 = 127, Q_R = 130;
+constexpr int Q_STAGE = 137;
+// Q_SC rows: R0 ru0 bza bzm bu (2 spare)
+constexpr int CHUNK = 8;                // collocation steps per wavefront of q_trial_eval
+constexpr int NPART = 9;                // rd cinf pmin pmax l1 zsum rth c1 sl
+
+// ---- per-lane scalar rows (after the step records of the tile) -----------------------------------
+enum {
+  X_STATE, X_ITERS, X_STATUS, X_FBUF, X_LS, X_FIRST,
+  X_S,                       // 10: th zlt zut s1 s2 zs1 zs2 nu3 nu1 nu2 (accepted iterate)
+  X_T = X_S + 10,            // 10: trial scalars
+  X_D = X_T + 10,            // 10: step scalars
+  X_MU = X_D + 10, X_NUP, X_DW, X_DWL, X_ALPHA, X_ADU, X_PHI0, X_DM, X_C1, X_SL,
+  X_DTH, X_DNU3, X_SIG1, X_SIG2, X_RS1, X_RS2, X_CUR, X_RTH,
+  NSCAL
+};
+enum { ST_TRIAL = 0, ST_FACTOR = 1, ST_FACTORED = 2, ST_DONE = 3 };
+
+using QTile = TileT<Q_STAGE>;
+
+struct Geo {      // geometry of the workspace
+  int K, nch;
+  __host__ __device__ size_t tile_doubles() const {
+    return ((size_t)K * Q_STAGE + NSCAL + (size_t)nch * NPART) * WAVE;
+  }
+};
+ASC_DEV gdbl *scal_base(const QTile &t_, const Geo &g) { return t_.base + (size_t)g.K * Q_STAGE * WAVE; }
+ASC_DEV gdbl *part_base(const QTile &t_, const Geo &g, int chunk) {
+  return t_.base + ((size_t)g.K * Q_STAGE + NSCAL + (size_t)chunk * NPART) * WAVE;
+}
+#define SC(r) ROW(sc, r)
+
+ASC_DEV Scal load_scal(const QTile &t_, const gdbl *sc, int r0) {
+  Scal s;
+  s.th = SC(r0 + S_TH); s.zlt = SC(r0 + S_ZLT); s.zut = SC(r0 + S_ZUT); s.s1 = SC(r0 + S_S1);
+  s.s2 = SC(r0 + S_S2); s.zs1 = SC(r0 + S_ZS1); s.zs2 = SC(r0 + S_ZS2); s.nu3 = SC(r0 + S_NU3);
+  s.nu1 = SC(r0 + S_NU1); s.nu2 = SC(r0 + S_NU2);
+  return s;
+}
+ASC_DEV void store_scal(const QTile &t_, gdbl *sc, int r0, const Scal &s) {
+  SC(r0 + S_TH) = s.th; SC(r0 + S_ZLT) = s.zlt; SC(r0 + S_ZUT) = s.zut; SC(r0 + S_S1) = s.s1;
+  SC(r0 + S_S2) = s.s2; SC(r0 + S_ZS1) = s.zs1; SC(r0 + S_ZS2) = s.zs2; SC(r0 + S_NU3) = s.nu3;
+  SC(r0 + S_NU1) = s.nu1; SC(r0 + S_NU2) = s.nu2;
+}
+
+// trial scalars  s + alpha*ds  (primal / equality multipliers) and clipped bound multipliers
+ASC_DEV Scal trial_scal(const Der &d, const Scal &s, const Scal &ds, double alpha, double adu, double mu,
+                        bool first) {
+  Scal t = s;
+  if (first) return t;
+  t.th += alpha * ds.th; t.s1 += alpha * ds.s1; t.s2 += alpha * ds.s2;
+  t.nu3 += alpha * ds.nu3; t.nu1 += alpha * ds.nu1; t.nu2 += alpha * ds.nu2;
+  t.zlt = clipz(s.zlt + adu * ds.zlt, t.th - d.tlb, mu);
+  t.zut = clipz(s.zut + adu * ds.zut, d.tub - t.th, mu);
+  t.zs1 = clipz(s.zs1 + adu * ds.zs1, t.s1, mu);
+  t.zs2 = clipz(s.zs2 + adu * ds.zs2, t.s2, mu);
+  return t;
+}
+
+// ==============================================================================================
+// q_init: initial point into iterate buffer 0, zero step, per-lane state
+// ==============================================================================================
+__global__ __launch_bounds__(WAVE) void q_init(const ascent_params *params, long batch, Geo g, double *ws,
+                                               const double *guess, int warm, double mu_init) {
+  const long p = (long)blockIdx.x * WAVE + threadIdx.x;
+  if (p >= batch) return;
+  const QTile t_((gdbl *)ws + (size_t)blockIdx.x * g.tile_doubles());
+  const Der d = derive(params[p]);
+  const int K = g.K;
+  gdbl *sc = scal_base(t_, g);
+  Scal s;
+  if (warm) {
+    for (int k = 0; k < K; k++) {
+      gdbl *sp = t_.st(k);
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) {
+        ROW(sp, Q_IT + O_Z + i) = guess[(7L * k + i) * batch + p];
+        ROW(sp, Q_IT + O_L + i) = guess[(8L * K + 7L * k + i) * batch + p];
+      }
+      ROW(sp, Q_IT + O_U) = guess[(7L * K + k) * batch + p];
+      ASC_UNROLL
+      for (int b = 0; b < 6; b++) ROW(sp, Q_IT + O_ZB + b) = guess[(15L * K + 6L * k + b) * batch + p];
+    }
+    const double *gs = guess + (21L * K) * batch + p;
+    s.th = gs[S_TH * batch]; s.zlt = gs[S_ZLT * batch]; s.zut = gs[S_ZUT * batch]; s.s1 = gs[S_S1 * batch];
+    s.s2 = gs[S_S2 * batch]; s.zs1 = gs[S_ZS1 * batch]; s.zs2 = gs[S_ZS2 * batch]; s.nu3 = gs[S_NU3 * batch];
+    s.nu1 = gs[S_NU1 * batch]; s.nu2 = gs[S_NU2 * batch];
+  } else {   // cold start: straight-line states toward a tangential insertion point, u = 0
+    const double tf0 = 0.9, dr = 0.166, aend = 0.5, vp = sqrt(d.vp2), dt = (1.0 / K) * d.T * tf0;
+    const double sdr = sin(dr), cdr = cos(dr);
+    const double xf = -d.rhof * sdr, yf = d.rhof * cdr - d.rho0;
+    for (int k = 0; k < K; k++) {
+      const double fr = (double)(k + 1) / K;
+      gdbl *sp = t_.st(k);
+      const double z[7] = {fr * xf, fr * yf, -fr * vp * cdr, -fr * vp * sdr, fr * aend, aend / (K * dt),
+                           d.mrate * dt * (k + 1)};
+      stn<7>(t_, sp, Q_IT + O_Z, z);
+      ROW(sp, Q_IT + O_U) = 0.0;
+    }
+    s.th = tf0;
+  }
+  double zK[7];
+  for (int k = 0; k < K; k++) {
+    gdbl *sp = t_.st(k);
+    ROW(sp, Q_IT + O_Z + IA) = push_in(ROW(sp, Q_IT + O_Z + IA), 0.0, d.aub);
+    ROW(sp, Q_IT + O_Z + IM) = push_in(ROW(sp, Q_IT + O_Z + IM), 0.0, 1.0);
+    ROW(sp, Q_IT + O_U) = push_in(ROW(sp, Q_IT + O_U), -1.0, 1.0);
+    if (warm != 2) {
+      ASC_UNROLL
+      for (int b = 0; b < 6; b++) ROW(sp, Q_IT + O_ZB + b) = 1.0;
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) ROW(sp, Q_IT + O_L + i) = 0.0;
+    } else {
+      ASC_UNROLL
+      for (int b = 0; b < 6; b++) ROW(sp, Q_IT + O_ZB + b) = fmax(ROW(sp, Q_IT + O_ZB + b), 1e-12);
+    }
+    ASC_UNROLL
+    for (int r = 0; r < 21; r++) ROW(sp, Q_ST + r) = 0.0;
+    if (k == K - 1) ldn<7>(t_, sp, Q_IT + O_Z, zK);
+  }
+  s.th = push_in(s.th, d.tlb, d.tub);
+  const Terminal tm = terminal_eval(d, zK);
+  if (warm != 2) {
+    s.s1 = fmax(tm.g1, 1e-2); s.s2 = fmax(tm.g2, 1e-2);
+    s.zlt = s.zut = s.zs1 = s.zs2 = 1.0;
+    s.nu3 = s.nu1 = s.nu2 = 0.0;
+  } else {
+    s.s1 = fmax(s.s1, 1e-10); s.s2 = fmax(s.s2, 1e-10);
+    s.zlt = fmax(s.zlt, 1e-12); s.zut = fmax(s.zut, 1e-12);
+    s.zs1 = fmax(s.zs1, 1e-12); s.zs2 = fmax(s.zs2, 1e-12);
+  }
+  for (int r = 0; r < NSCAL; r++) SC(r) = 0.0;
+  store_scal(t_, sc, X_S, s);
+  SC(X_STATE) = ST_TRIAL; SC(X_FIRST) = 1.0; SC(X_STATUS) = ASCENT_MAX_ITER;
+  SC(X_MU) = mu_init; SC(X_NUP) = 1.0;
+}
+
+// per-lane iterate buffer: lanes advance asynchronously, so which of the two iterate buffers holds a
+// lane's current iterate is per-lane state (X_CUR); its rows are reached through a per-lane offset
+#define ROWO(p, r, off) (p)[(r) * WAVE + (off)]
+template <int N>
+ASC_DEV void ldo(const gdbl *p, int r0, unsigned off, double *v) {
+  ASC_UNROLL
+  for (int i = 0; i < N; i++) v[i] = ROWO(p, r0 + i, off);
+}
+template <int N>
+ASC_DEV void sto(gdbl *p, int r0, unsigned off, const double *v) {
+  ASC_UNROLL
+  for (int i = 0; i < N; i++) ROWO(p, r0 + i, off) = v[i];
+}
+ASC_DEV unsigned buf_off(const QTile &t_, int buf) { return t_.lane + (unsigned)buf * (21 * WAVE); }
+
+// ==============================================================================================
+// q_trial_eval: one wavefront = 64 NLPs x CHUNK consecutive steps
+// ==============================================================================================
+__global__ __launch_bounds__(WAVE) void q_trial_eval(const ascent_params *params, long batch, Geo g,
+                                                     double *ws) {
+  const long p = (long)blockIdx.x * WAVE + threadIdx.x;
+  if (p >= batch) return;
+  const QTile t_((gdbl *)ws + (size_t)blockIdx.x * g.tile_doubles());
+  gdbl *sc = scal_base(t_, g);
+  if ((int)SC(X_STATE) != ST_TRIAL) return;
+  const Der d = derive(params[p]);
+  const int K = g.K, chunk = blockIdx.y;
+  const int k_lo = chunk * CHUNK, k_hi = min(K, k_lo + CHUNK) - 1;
+  const bool first = SC(X_FIRST) != 0.0;
+  const double alpha = SC(X_ALPHA), adu = SC(X_ADU), mu = SC(X_MU);
+  const Scal s = load_scal(t_, sc, X_S), ds = load_scal(t_, sc, X_D);
+  const Scal st = trial_scal(d, s, ds, alpha, adu, mu, first);
+  const double hT = (1.0 / K) * d.T, dt = hT * st.th, be = dt * d.alpha;
+  const int cur = (int)SC(X_CUR);
+  const unsigned oc = buf_off(t_, cur), on = buf_off(t_, 1 - cur);   // current / trial iterate rows
+  const double mlo = mu * 1e-10, mhi = mu * 1e10;
+
+  double z[7], ln[7];
+  {   // trial state of the chunk's last step, trial multipliers of the step after it
+    const gdbl *sp = t_.st(k_hi);
+    double dz[7];
+    ldo<7>(sp, Q_IT + O_Z, oc, z);
+    ldn<7>(t_, sp, Q_ST + O_Z, dz);
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) z[i] += alpha * dz[i];
+    if (k_hi + 1 < K) {
+      const gdbl *sn = t_.st(k_hi + 1);
+      double dl[7];
+      ldo<7>(sn, Q_IT + O_L, oc, ln);
+      ldn<7>(t_, sn, Q_ST + O_L, dl);
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) ln[i] += alpha * dl[i];
+    } else {
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) ln[i] = 0.0;
+    }
+  }
+  double rd = 0.0, cinf = 0.0, pmin = 1e300, pmax = -1e300, l1 = 0.0, zsum = 0.0, rth = 0.0, c1 = 0.0, sl = 0.0;
+  for (int k = k_hi; k >= k_lo; k--) {
+    gdbl *sp = t_.st(k);
+    double zp[7], l[7], zb[6], tmp7[7], tmp6[6];
+    ldo<7>(sp, Q_IT + O_L, oc, l);
+    ldn<7>(t_, sp, Q_ST + O_L, tmp7);
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) l[i] += alpha * tmp7[i];
+    const double u = ROWO(sp, Q_IT + O_U, oc) + alpha * ROW(sp, Q_ST + O_U);
+    ldo<6>(sp, Q_IT + O_ZB, oc, zb);
+    ldn<6>(t_, sp, Q_ST + O_ZB, tmp6);
+    const double a = z[IA], m = z[IM];
+    const double dist[6] = {a, d.aub - a, m, 1.0 - m, u + 1.0, 1.0 - u};
+    double id[6];
+    ASC_UNROLL
+    for (int b = 0; b < 6; b++) {
+      id[b] = rcp(dist[b]);
+      if (!first) zb[b] = fmin(fmax(zb[b] + adu * tmp6[b], mlo * id[b]), mhi * id[b]);
+    }
+    if (k > 0) {
+      const gdbl *spp = t_.st(k - 1);
+      ldo<7>(spp, Q_IT + O_Z, oc, zp);
+      ldn<7>(t_, spp, Q_ST + O_Z, tmp7);
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) zp[i] += alpha * tmp7[i];
+    } else {
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) zp[i] = 0.0;
+    }
+    // the trial iterate of this step
+    sto<7>(sp, Q_IT + O_Z, on, z);
+    ROWO(sp, Q_IT + O_U, on) = u;
+    sto<7>(sp, Q_IT + O_L, on, l);
+    sto<6>(sp, Q_IT + O_ZB, on, zb);
+    // node evaluation (Launch_Optimiser.py:114-136) with Jacobian and Lagrangian-Hessian blocks
+    double G[8], E[4], H[10], F[7], fl[7], ax, ay;
+    accel<2>(d, z[IX], z[IY], z[IA], z[IM], -dt * l[IVX], -dt * l[IVY], ax, ay, G, H);
+    rhs_f(d, z, u, ax, ay, F);
+    implicit_block(G, dt, E);
+    fzt_lambda(G, l, fl);
+    double rz[7], gt[7], cc[7];
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) {
+      rz[i] = l[i] - dt * fl[i] - ln[i];
+      gt[i] = -hT * fl[i];
+      cc[i] = z[i] - zp[i] - dt * F[i];
+      c1 += fabs(cc[i]);
+      cinf = fmax(cinf, fabs(cc[i]));
+      rth -= hT * F[i] * l[i];
+      l1 += fabs(l[i]);
+    }
+    // Hessian block with the bound-barrier curvature of angle and mass folded in
+    H[7] += zb[0] * id[0] + zb[1] * id[1];
+    H[9] += zb[2] * id[2] + zb[3] * id[3];
+    stn<8>(t_, sp, Q_G, G);
+    stn<4>(t_, sp, Q_E, E);
+    stn<10>(t_, sp, Q_H, H);
+    stn<7>(t_, sp, Q_F, F);
+    stn<7>(t_, sp, Q_C, cc);
+    stn<7>(t_, sp, Q_RZ, rz);
+    stn<7>(t_, sp, Q_GT, gt);
+    const double scr[5] = {zb[4] * id[4] + zb[5] * id[5], -be * l[IW], id[1] - id[0], id[3] - id[2],
+                           id[5] - id[4]};
+    stn<5>(t_, sp, Q_SC, scr);
+    // KKT error pieces (dual residual with the actual bound multipliers) and merit pieces
+    double r[7];
+    cpy<7>(r, rz);
+    r[IA] += zb[1] - zb[0];
+    r[IM] += zb[3] - zb[2];
+    if (k == K - 1) {
+      const Terminal t = terminal_eval(d, z);
+      r[IX] += st.nu3 * t.e3g[0] + st.nu1 * t.g1g[0];
+      r[IY] += st.nu3 * t.e3g[1] + st.nu1 * t.g1g[1];
+      r[IVX] += st.nu3 * t.e3g[2] + st.nu2 * t.g2g[0];
+      r[IVY] += st.nu3 * t.e3g[3] + st.nu2 * t.g2g[1];
+      const double e1 = fabs(t.e3), e2 = fabs(t.g1 - st.s1), e3 = fabs(t.g2 - st.s2);
+      cinf = fmax(cinf, fmax(e1, fmax(e2, e3)));
+      c1 += e1 + e2 + e3;
+      const double ps = ((st.th - d.tlb) * (d.tub - st.th)) * (st.s1 * st.s2);
+      sl += ps > 0.0 ? log(ps) : NAN;
+      store_scal(t_, sc, X_T, st);
+    }
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) rd = fmax(rd, fabs(r[i]));
+    rd = fmax(rd, fabs(-be * l[IW] - zb[4] + zb[5]));
+    ASC_UNROLL
+    for (int b = 0; b < 6; b++) {
+      const double pr = dist[b] * zb[b];
+      pmin = fmin(pmin, pr);
+      pmax = fmax(pmax, pr);
+      zsum += zb[b];
+    }
+    const double pa = dist[0] * dist[1], pm = dist[2] * dist[3], pu = dist[4] * dist[5];
+    sl += (pa > 0.0 && pm > 0.0 && pu > 0.0) ? log(pa * pm * pu) : NAN;
+    cpy<7>(ln, l);
+    cpy<7>(z, zp);
+  }
+  gdbl *pp = part_base(t_, g, chunk);
+  ROW(pp, 0) = rd; ROW(pp, 1) = cinf; ROW(pp, 2) = pmin; ROW(pp, 3) = pmax; ROW(pp, 4) = l1;
+  ROW(pp, 5) = zsum; ROW(pp, 6) = rth; ROW(pp, 7) = c1; ROW(pp, 8) = sl;
+}
+
+// ==============================================================================================
+// q_decide_factor: per-lane decisions, then the backward factorisation
+// ==============================================================================================
+struct InQM {   // matrix part of a step record (double-buffered one step ahead)
+  double G[8], E[4], H[10], R0;
+};
+struct InQV {   // vector part (loaded at the top of the step, consumed after the congruence)
+  double rz[7], gt[7], cc[7], F[7], ru0, bza, bzm, bu;
+};
+ASC_DEV void loadQM(const QTile &t_, int k, InQM &in) {
+  const gdbl *sp = t_.st(k);
+  ldn<8>(t_, sp, Q_G, in.G);
+  ldn<4>(t_, sp, Q_E, in.E);
+  ldn<10>(t_, sp, Q_H, in.H);
+  in.R0 = ROW(sp, Q_SC);
+}
+ASC_DEV void loadQV(const QTile &t_, int k, InQV &in) {
+  const gdbl *sp = t_.st(k);
+  ldn<7>(t_, sp, Q_RZ, in.rz);
+  ldn<7>(t_, sp, Q_GT, in.gt);
+  ldn<7>(t_, sp, Q_C, in.cc);
+  ldn<7>(t_, sp, Q_F, in.F);
+  in.ru0 = ROW(sp, Q_SC + 1); in.bza = ROW(sp, Q_SC + 2); in.bzm = ROW(sp, Q_SC + 3); in.bu = ROW(sp, Q_SC + 4);
+}
+
+__global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *params, long batch, Geo g,
+                                                        double *ws, int max_iter, double tol, int *counters) {
+  const long p = (long)blockIdx.x * WAVE + threadIdx.x;
+  if (p >= batch) return;
+  const QTile t_((gdbl *)ws + (size_t)blockIdx.x * g.tile_doubles());
+  gdbl *sc = scal_base(t_, g);
+  int state = (int)SC(X_STATE);
+  if (state == ST_DONE) return;
+  const Der d = derive(params[p]);
+  const int K = g.K;
+  double mu = SC(X_MU);
+  if (state == ST_TRIAL) {
+    // ---- reduce the partials of the trial point -------------------------------------------------
+    double rd = 0.0, cinf = 0.0, pmin = 1e300, pmax = -1e300, l1 = 0.0, zsum = 0.0, rth = 1.0, c1 = 0.0, sl = 0.0;
+    for (int c = g.nch - 1; c >= 0; c--) {
+      const gdbl *pp = part_base(t_, g, c);
+      rd = fmax(rd, ROW(pp, 0)); cinf = fmax(cinf, ROW(pp, 1));
+      pmin = fmin(pmin, ROW(pp, 2)); pmax = fmax(pmax, ROW(pp, 3));
+      l1 += ROW(pp, 4); zsum += ROW(pp, 5); rth += ROW(pp, 6); c1 += ROW(pp, 7); sl += ROW(pp, 8);
+    }
+    const bool first = SC(X_FIRST) != 0.0;
+    const Scal st = load_scal(t_, sc, X_T);
+    double nu_pen = SC(X_NUP);
+    if (!first) {   // Armijo test on the l1 merit function
+      const double alpha = SC(X_ALPHA), phi0 = SC(X_PHI0), Dm = SC(X_DM);
+      const double phit = st.th - mu * sl + nu_pen * c1;
+      if (!(isfinite(phit) && phit <= phi0 + 1e-8 * alpha * Dm + 2.220446049250313e-15 * fabs(phi0))) {
+        const int ls = (int)SC(X_LS) + 1;
+        SC(X_LS) = ls;
+        if (ls >= 40) {
+          SC(X_STATUS) = ASCENT_LINESEARCH_FAILED; SC(X_STATE) = ST_DONE;
+        } else {
+          SC(X_ALPHA) = 0.5 * alpha;       // stays in ST_TRIAL: re-evaluated in the next round
+          atomicAdd(&counters[0], 1);
+        }
+        return;
+      }
+      SC(X_ITERS) = SC(X_ITERS) + 1.0;
+    }
+    // ---- accepted: the trial point is the iterate ---------------------------------------------------
+    store_scal(t_, sc, X_S, st);
+    SC(X_CUR) = 1.0 - SC(X_CUR);
+    SC(X_FIRST) = 0.0; SC(X_C1) = c1; SC(X_SL) = sl; SC(X_LS) = 0.0; SC(X_RTH) = rth;
+    ErrParts e;
+    e.rd = fmax(rd, fabs(rth - st.zlt + st.zut));
+    e.rd = fmax(e.rd, fmax(fabs(-st.nu1 - st.zs1), fabs(-st.nu2 - st.zs2)));
+    e.cinf = cinf;
+    const double pr[4] = {(st.th - d.tlb) * st.zlt, (d.tub - st.th) * st.zut, st.s1 * st.zs1, st.s2 * st.zs2};
+    ASC_UNROLL
+    for (int j = 0; j < 4; j++) { pmin = fmin(pmin, pr[j]); pmax = fmax(pmax, pr[j]); }
+    e.pmin = pmin; e.pmax = pmax;
+    l1 += fabs(st.nu3) + fabs(st.nu1) + fabs(st.nu2);
+    zsum += st.zlt + st.zut + st.zs1 + st.zs2;
+    e.sd = fmax(100.0, (l1 + zsum) / (double)(13 * K + 7)) * 0.01;
+    if (e.err(0.0) <= tol) {
+      SC(X_STATUS) = ASCENT_CONVERGED; SC(X_STATE) = ST_DONE;
+      return;
+    }
+    if ((int)SC(X_ITERS) >= max_iter) {
+      SC(X_STATUS) = ASCENT_MAX_ITER; SC(X_STATE) = ST_DONE;
+      return;
+    }
+    while (mu > tol * 0.1 && e.err(mu) <= 10.0 * mu) {
+      mu = fmax(tol * 0.1, fmin(0.2 * mu, mu * sqrt(mu)));
+      nu_pen = 1.0;
+    }
+    SC(X_MU) = mu; SC(X_NUP) = nu_pen; SC(X_DW) = 0.0;
+    state = ST_FACTOR;
+  } else if (state == ST_FACTORED) {
+    atomicAdd(&counters[1], 1);
+    return;
+  }
+  // ---- backward factorisation at the current iterate, primal regularisation dw ---------------------
+  const unsigned oc = buf_off(t_, (int)SC(X_CUR));
+  const Scal s = load_scal(t_, sc, X_S);
+  const double dw = SC(X_DW);
+  const double hT = (1.0 / K) * d.T, dt = hT * s.th, be = dt * d.alpha, ith = rcp(s.th);
+  double P[28], p0[7], p1[7], p2[7];
+  ASC_UNROLL
+  for (int i = 0; i < 28; i++) P[i] = 0.0;
+  ASC_UNROLL
+  for (int i = 0; i < 7; i++) { p0[i] = p1[i] = p2[i] = 0.0; }
+  double S10 = 0.0, S11 = 0.0, S12 = 0.0, S20 = 0.0, S22 = 0.0;
+  double zK[7];
+  ldo<7>(t_.st(K - 1), Q_IT + O_Z, oc, zK);
+  const Terminal tm = terminal_eval(d, zK);
+  const double is1 = rcp(s.s1), is2 = rcp(s.s2);
+  const double sig1 = s.zs1 * is1 + dw, sig2 = s.zs2 * is2 + dw;
+  const double rs1 = -mu * is1 - s.nu1, rs2 = -mu * is2 - s.nu2;
+  const double cg1 = tm.g1 - s.s1, cg2 = tm.g2 - s.s2;
+  int bad = 0;
+  auto body = [&](InQM &cm, int k) __attribute__((always_inline)) {
+    gdbl *sp = t_.st(k);
+    InQV cv;
+    loadQV(t_, k, cv);                    // in flight while the congruence runs
+    const double *G = cm.G, *E = cm.E, *H = cm.H;
+    P[sid(IX, IX)] += H[0]; P[sid(IX, IY)] += H[1]; P[sid(IX, IA)] += H[2]; P[sid(IX, IM)] += H[3];
+    P[sid(IY, IY)] += H[4]; P[sid(IY, IA)] += H[5]; P[sid(IY, IM)] += H[6];
+    P[sid(IA, IA)] += H[7]; P[sid(IA, IM)] += H[8]; P[sid(IM, IM)] += H[9];
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) P[sid(i, i)] += dw;
+    if (k == K - 1) terminal_hessian(P, tm, s.nu3, s.nu1, s.nu2, sig1, sig2);
+    congruence(P, G, E, dt);
+    const double D = cm.R0 + dw + be * be * P[sid(IW, IW)];
+    if (!(D > 0.0)) bad = 1;
+    const double iD = rcp(D);
+    double mw[7], kap[7];
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) { mw[i] = be * P[sid(i, IW)]; kap[i] = mw[i] * iD; }
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) {
+      ASC_UNROLL
+      for (int j = i; j < 7; j++) P[sid(i, j)] -= mw[i] * kap[j];
+    }
+    stn<7>(t_, sp, Q_KA, kap);
+    // right-hand sides 0: residual, 1: -B_theta, 2: -B_nu3
+    double *rz = cv.rz;
+    const double *cc = cv.cc;
+    rz[IA] += mu * cv.bza;
+    rz[IM] += mu * cv.bzm;
+    const double ru = cv.ru0 + mu * cv.bu;
+    const double gu = cv.ru0 * ith;
+    if (k == K - 1) {
+      const double w1 = s.nu1 + sig1 * cg1 + rs1, w2 = s.nu2 + sig2 * cg2 + rs2;
+      rz[IX] += s.nu3 * tm.e3g[0] + w1 * tm.g1g[0];
+      rz[IY] += s.nu3 * tm.e3g[1] + w1 * tm.g1g[1];
+      rz[IVX] += s.nu3 * tm.e3g[2] + w2 * tm.g2g[0];
+      rz[IVY] += s.nu3 * tm.e3g[3] + w2 * tm.g2g[1];
+    }
+    double n[7], nt[7], q0[7], q1[7], rc1[7], Prc[7], k00, k01, k02;
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) n[i] = -rz[i] + p0[i];
+    solveAT(G, E, dt, n, nt);
+    k00 = (be * nt[IW] - ru) * iD;
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) { q0[i] = nt[i] - mw[i] * k00; n[i] = -cc[i]; }
+    symv(P, n, Prc);
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) p0[i] = q0[i] - Prc[i];
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) n[i] = -cv.gt[i] + p1[i];
+    solveAT(G, E, dt, n, nt);
+    k01 = (be * nt[IW] - gu) * iD;
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) { q1[i] = nt[i] - mw[i] * k01; rc1[i] = hT * cv.F[i]; }
+    symv(P, rc1, Prc);
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) p1[i] = q1[i] - Prc[i];
+    cpy<7>(n, p2);
+    if (k == K - 1) { n[IX] -= tm.e3g[0]; n[IY] -= tm.e3g[1]; n[IVX] -= tm.e3g[2]; n[IVY] -= tm.e3g[3]; }
+    solveAT(G, E, dt, n, nt);
+    k02 = be * nt[IW] * iD;
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) p2[i] = nt[i] - mw[i] * k02;
+    ROW(sp, Q_K0) = k00; ROW(sp, Q_K0 + 1) = k01; ROW(sp, Q_K0 + 2) = k02;
+    double a10 = D * k01 * k00, a11 = D * k01 * k01, a12 = D * k01 * k02, a20 = D * k02 * k00;
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) {
+      a10 += 0.5 * (rc1[i] * (q0[i] + p0[i]) - cc[i] * (q1[i] + p1[i]));
+      a11 += rc1[i] * (q1[i] + p1[i]);
+      a12 += rc1[i] * p2[i];
+      a20 -= cc[i] * p2[i];
+    }
+    S10 += a10; S11 += a11; S12 += a12; S20 += a20; S22 += D * k02 * k02;
+  };
+#define LD_(k_, buf_) loadQM(t_, k_, buf_)
+  ASC_SWEEP_BACKWARD(InQM, LD_, body)
+#undef LD_
+  int ok = !bad;
+  double dth = 0.0, dnu3 = 0.0;
+  if (ok) {
+    const double itl = rcp(s.th - d.tlb), itu = rcp(d.tub - s.th);
+    const double rthp = SC(X_RTH) + mu * (itu - itl);   // d/dtheta of the barrier Lagrangian
+    const double sth = s.zlt * itl + s.zut * itu + dw;
+    const double a11 = sth - S11, a12 = -S12, a22 = -S22;
+    const double b1 = -rthp + S10, b2 = -tm.e3 + S20;
+    const double det = a11 * a22 - a12 * a12;
+    if (det < 0.0) {
+      const double idet = 1.0 / det;
+      dth = (b1 * a22 - a12 * b2) * idet;
+      dnu3 = (a11 * b2 - a12 * b1) * idet;
+    } else {
+      ok = 0;
+    }
+  }
+  if (ok) {
+    SC(X_DTH) = dth; SC(X_DNU3) = dnu3; SC(X_SIG1) = sig1; SC(X_SIG2) = sig2; SC(X_RS1) = rs1; SC(X_RS2) = rs2;
+    SC(X_DWL) = dw;
+    SC(X_STATE) = ST_FACTORED;
+    atomicAdd(&counters[1], 1);
+  } else {   // wrong inertia: raise the primal regularisation; factorised again in the next round
+    const double dwl = SC(X_DWL);
+    const double ndw = dw == 0.0 ? fmax(1e-4, dwl / 3.0) : dw * 8.0;
+    if (ndw > 1e10) {
+      SC(X_STATUS) = ASCENT_REGULARISATION_FAILED; SC(X_STATE) = ST_DONE;
+    } else {
+      SC(X_DW) = ndw; SC(X_STATE) = ST_FACTOR;
+      atomicAdd(&counters[0], 1);
+    }
+  }
+}
+
+// ==============================================================================================
+// q_forward: the forward recurrence only (primal step dz, du)
+// ==============================================================================================
+struct InQF {
+  double G[8], E[4], cc[7], F[7], ka[7], k0[3];
+};
+ASC_DEV void loadQF(const QTile &t_, int k, InQF &in) {
+  const gdbl *sp = t_.st(k);
+  ldn<8>(t_, sp, Q_G, in.G);
+  ldn<4>(t_, sp, Q_E, in.E);
+  ldn<7>(t_, sp, Q_C, in.cc);
+  ldn<7>(t_, sp, Q_F, in.F);
+  ldn<7>(t_, sp, Q_KA, in.ka);
+  ldn<3>(t_, sp, Q_K0, in.k0);
+}
+
+__global__ __launch_bounds__(WAVE) void q_forward(const ascent_params *params, long batch, Geo g, double *ws) {
+  const long p = (long)blockIdx.x * WAVE + threadIdx.x;
+  if (p >= batch) return;
+  const QTile t_((gdbl *)ws + (size_t)blockIdx.x * g.tile_doubles());
+  gdbl *sc = scal_base(t_, g);
+  if ((int)SC(X_STATE) != ST_FACTORED) return;
+  const Der d = derive(params[p]);
+  const int K = g.K;
+  const double th = SC(X_S + S_TH), dth = SC(X_DTH), dnu3 = SC(X_DNU3);
+  const double hT = (1.0 / K) * d.T, dt = hT * th, be = dt * d.alpha;
+  double dzp[7];
+  ASC_UNROLL
+  for (int i = 0; i < 7; i++) dzp[i] = 0.0;
+  auto body = [&](InQF &cur_, int k) __attribute__((always_inline)) {
+    gdbl *sp = t_.st(k);
+    double xi[7], dz[7];
+    double du = cur_.k0[0] + cur_.k0[1] * dth + cur_.k0[2] * dnu3;
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) {
+      xi[i] = dzp[i] - cur_.cc[i] + hT * cur_.F[i] * dth;
+      du -= cur_.ka[i] * xi[i];
+    }
+    xi[IW] += be * du;
+    solveA(cur_.G, cur_.E, dt, xi, dz);
+    stn<7>(t_, sp, Q_ST + O_Z, dz);
+    ROW(sp, Q_ST + O_U) = du;
+    cpy<7>(dzp, dz);
+  };
+#define LD_(k_, buf_) loadQF(t_, k_, buf_)
+  ASC_SWEEP_FORWARD4(InQF, LD_, body)
+#undef LD_
+}
+
+// ==============================================================================================
+// q_local: everything of the step that has no recurrence -- adjoint right-hand side, bound-multiplier
+// steps, both fraction-to-boundary rules, barrier slope.  One wavefront = 64 NLPs x CHUNK steps.
+// ==============================================================================================
+__global__ __launch_bounds__(WAVE) void q_local(const ascent_params *params, long batch, Geo g, double *ws) {
+  const long p = (long)blockIdx.x * WAVE + threadIdx.x;
+  if (p >= batch) return;
+  const QTile t_((gdbl *)ws + (size_t)blockIdx.x * g.tile_doubles());
+  gdbl *sc = scal_base(t_, g);
+  if ((int)SC(X_STATE) != ST_FACTORED) return;
+  const Der d = derive(params[p]);
+  const int K = g.K, chunk = blockIdx.y;
+  const int k_lo = chunk * CHUNK, k_hi = min(K, k_lo + CHUNK) - 1;
+  const unsigned oc = buf_off(t_, (int)SC(X_CUR));
+  const Scal s = load_scal(t_, sc, X_S);
+  const double mu = SC(X_MU), dw = SC(X_DWL), dth = SC(X_DTH), dnu3 = SC(X_DNU3);
+  const double tau = fmax(0.99, 1.0 - mu);
+  double rmax = 0.0, gsum = 0.0, adu = 1.0, ccl = 0.0;
+  for (int k = k_lo; k <= k_hi; k++) {
+    gdbl *sp = t_.st(k);
+    double H[10], rz[7], gt[7], dz[7], zb[6];
+    {   // defects . multipliers, half of the curvature estimate c'(lambda + dlambda)
+      double cc[7], l[7];
+      ldn<7>(t_, sp, Q_C, cc);
+      ldo<7>(sp, Q_IT + O_L, oc, l);
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) ccl += cc[i] * l[i];
+    }
+    ldn<10>(t_, sp, Q_H, H);
+    ldn<7>(t_, sp, Q_RZ, rz);
+    ldn<7>(t_, sp, Q_GT, gt);
+    ldn<7>(t_, sp, Q_ST + O_Z, dz);
+    ldo<6>(sp, Q_IT + O_ZB, oc, zb);
+    const double du = ROW(sp, Q_ST + O_U);
+    const double bza = ROW(sp, Q_SC + 2), bzm = ROW(sp, Q_SC + 3);
+    const double a = ROWO(sp, Q_IT + O_Z + IA, oc), m = ROWO(sp, Q_IT + O_Z + IM, oc), u = ROWO(sp, Q_IT + O_U, oc);
+    // right-hand side of the adjoint recursion: -(rz + gt*dtheta) - Q dz   (dlambda_{k+1} is added by q_adjoint)
+    double r[7];
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) r[i] = -rz[i] - gt[i] * dth - dw * dz[i];
+    r[IA] -= mu * bza;
+    r[IM] -= mu * bzm;
+    r[IX] -= H[0] * dz[IX] + H[1] * dz[IY] + H[2] * dz[IA] + H[3] * dz[IM];
+    r[IY] -= H[1] * dz[IX] + H[4] * dz[IY] + H[5] * dz[IA] + H[6] * dz[IM];
+    r[IA] -= H[2] * dz[IX] + H[5] * dz[IY] + H[7] * dz[IA] + H[8] * dz[IM];
+    r[IM] -= H[3] * dz[IX] + H[6] * dz[IY] + H[8] * dz[IA] + H[9] * dz[IM];
+    if (k == K - 1) {
+      double zK[7], QT[28], qd[7];
+      ldo<7>(sp, Q_IT + O_Z, oc, zK);
+      const Terminal tm = terminal_eval(d, zK);
+      const double sig1 = SC(X_SIG1), sig2 = SC(X_SIG2), rs1 = SC(X_RS1), rs2 = SC(X_RS2);
+      ASC_UNROLL
+      for (int i = 0; i < 28; i++) QT[i] = 0.0;
+      terminal_hessian(QT, tm, s.nu3, s.nu1, s.nu2, sig1, sig2);
+      symv(QT, dz, qd);
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) r[i] -= qd[i];
+      const double w1 = s.nu1 + sig1 * (tm.g1 - s.s1) + rs1, w2 = s.nu2 + sig2 * (tm.g2 - s.s2) + rs2;
+      r[IX] -= s.nu3 * tm.e3g[0] + w1 * tm.g1g[0] + tm.e3g[0] * dnu3;
+      r[IY] -= s.nu3 * tm.e3g[1] + w1 * tm.g1g[1] + tm.e3g[1] * dnu3;
+      r[IVX] -= s.nu3 * tm.e3g[2] + w2 * tm.g2g[0] + tm.e3g[2] * dnu3;
+      r[IVY] -= s.nu3 * tm.e3g[3] + w2 * tm.g2g[1] + tm.e3g[3] * dnu3;
+    }
+    stn<7>(t_, sp, Q_R, r);
+    const double id[6] = {rcp(a), rcp(d.aub - a), rcp(m), rcp(1.0 - m), rcp(u + 1.0), rcp(1.0 - u)};
+    ASC_FTBR(rmax, id[0], dz[IA]); ASC_FTBR(rmax, id[1], -dz[IA]);
+    ASC_FTBR(rmax, id[2], dz[IM]); ASC_FTBR(rmax, id[3], -dz[IM]);
+    ASC_FTBR(rmax, id[4], du); ASC_FTBR(rmax, id[5], -du);
+    gsum += dz[IA] * (id[1] - id[0]) + dz[IM] * (id[3] - id[2]) + du * (id[5] - id[4]);
+    const double dx[3] = {dz[IA], dz[IM], du};
+    double dzb[6];
+    ASC_UNROLL
+    for (int b = 0; b < 3; b++) {
+      const double zl = zb[2 * b], zu = zb[2 * b + 1];
+      dzb[2 * b] = id[2 * b] * (mu - zl * dx[b]) - zl;
+      dzb[2 * b + 1] = id[2 * b + 1] * (mu + zu * dx[b]) - zu;
+      ASC_FTB(adu, zl, dzb[2 * b]);
+      ASC_FTB(adu, zu, dzb[2 * b + 1]);
+    }
+    stn<6>(t_, sp, Q_ST + O_ZB, dzb);
+  }
+  gdbl *pp = part_base(t_, g, chunk);       // reuse partial rows 0..2 (the trial partials are consumed by now)
+  ROW(pp, 0) = rmax; ROW(pp, 1) = gsum; ROW(pp, 2) = adu; ROW(pp, 3) = ccl;
+}
+
+// ==============================================================================================
+// q_adjoint: multiplier step, then the step-size / merit bookkeeping of the iteration
+// ==============================================================================================
+struct InQA {
+  double G[8], E[4], r[7], cc[7];
+};
+ASC_DEV void loadQA(const QTile &t_, int k, InQA &in) {
+  const gdbl *sp = t_.st(k);
+  ldn<8>(t_, sp, Q_G, in.G);
+  ldn<4>(t_, sp, Q_E, in.E);
+  ldn<7>(t_, sp, Q_R, in.r);
+  ldn<7>(t_, sp, Q_C, in.cc);
+}
+
+__global__ __launch_bounds__(WAVE) void q_adjoint(const ascent_params *params, long batch, Geo g, double *ws) {
+  const long p = (long)blockIdx.x * WAVE + threadIdx.x;
+  if (p >= batch) return;
+  const QTile t_((gdbl *)ws + (size_t)blockIdx.x * g.tile_doubles());
+  gdbl *sc = scal_base(t_, g);
+  if ((int)SC(X_STATE) != ST_FACTORED) return;
+  const Der d = derive(params[p]);
+  const int K = g.K;
+  const unsigned oc = buf_off(t_, (int)SC(X_CUR));
+  const Scal s = load_scal(t_, sc, X_S);
+  const double mu = SC(X_MU), dth = SC(X_DTH), dnu3 = SC(X_DNU3);
+  const double sig1 = SC(X_SIG1), sig2 = SC(X_SIG2), rs1 = SC(X_RS1), rs2 = SC(X_RS2);
+  const double hT = (1.0 / K) * d.T, dt = hT * s.th;
+  const double tau = fmax(0.99, 1.0 - mu);
+  double dln[7];
+  ASC_UNROLL
+  for (int i = 0; i < 7; i++) dln[i] = 0.0;
+  double cl = 0.0;
+  auto body = [&](InQA &cur_, int k) __attribute__((always_inline)) {
+    gdbl *sp = t_.st(k);
+    double r[7], dl[7];
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) r[i] = cur_.r[i] + dln[i];
+    solveAT(cur_.G, cur_.E, dt, r, dl);
+    stn<7>(t_, sp, Q_ST + O_L, dl);
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) cl += cur_.cc[i] * dl[i];
+    cpy<7>(dln, dl);
+  };
+#define LD_(k_, buf_) loadQA(t_, k_, buf_)
+  ASC_SWEEP_BACKWARD4(InQA, LD_, body)
+#undef LD_
+  // partials of q_local (chunks in forward order, as the fused kernel's forward pass accumulates)
+  double rmax = 0.0, gsum = 0.0, adu = 1.0;
+  for (int c = 0; c < g.nch; c++) {
+    const gdbl *pp = part_base(t_, g, c);
+    rmax = fmax(rmax, ROW(pp, 0)); gsum += ROW(pp, 1); adu = fmin(adu, ROW(pp, 2)); cl += ROW(pp, 3);
+  }
+  // scalars of the step
+  double zK[7], dzK[7];
+  ldo<7>(t_.st(K - 1), Q_IT + O_Z, oc, zK);
+  ldn<7>(t_, t_.st(K - 1), Q_ST + O_Z, dzK);
+  const Terminal tm = terminal_eval(d, zK);
+  Scal ds;
+  ds.th = dth; ds.nu3 = dnu3;
+  ds.s1 = (tm.g1 - s.s1) + tm.g1g[0] * dzK[IX] + tm.g1g[1] * dzK[IY];
+  ds.s2 = (tm.g2 - s.s2) + tm.g2g[0] * dzK[IVX] + tm.g2g[1] * dzK[IVY];
+  ds.nu1 = sig1 * ds.s1 + rs1;
+  ds.nu2 = sig2 * ds.s2 + rs2;
+  ds.zs1 = mu / s.s1 - s.zs1 - s.zs1 / s.s1 * ds.s1;
+  ds.zs2 = mu / s.s2 - s.zs2 - s.zs2 / s.s2 * ds.s2;
+  const double dl_ = s.th - d.tlb, dU = d.tub - s.th;
+  ds.zlt = mu / dl_ - s.zlt - s.zlt / dl_ * ds.th;
+  ds.zut = mu / dU - s.zut + s.zut / dU * ds.th;
+  double apr = 1.0;
+  if (rmax * apr > tau) apr = tau / rmax;
+  ASC_FTB(apr, dl_, ds.th); ASC_FTB(apr, dU, -ds.th);
+  ASC_FTB(apr, s.s1, ds.s1); ASC_FTB(apr, s.s2, ds.s2);
+  ASC_FTB(adu, s.zlt, ds.zlt); ASC_FTB(adu, s.zut, ds.zut);
+  ASC_FTB(adu, s.zs1, ds.zs1); ASC_FTB(adu, s.zs2, ds.zs2);
+  double gd = mu * gsum;
+  gd += ds.th * (1.0 - mu / dl_ + mu / dU) - mu * ds.s1 / s.s1 - mu * ds.s2 / s.s2;
+  cl += tm.e3 * (s.nu3 + ds.nu3) + (tm.g1 - s.s1) * (s.nu1 + ds.nu1) + (tm.g2 - s.s2) * (s.nu2 + ds.nu2);
+  // l1 merit: penalty update (Nocedal & Wright eq. 18.36), reference value, slope
+  const double c1 = SC(X_C1), slog = SC(X_SL);
+  double nu_pen = SC(X_NUP);
+  const double curv = -gd + cl;
+  if (c1 > 0.0) {
+    const double need = (gd + 0.5 * fmax(curv, 0.0)) / (0.9 * c1);
+    if (nu_pen < need) nu_pen = need + 1.0;
+  }
+  store_scal(t_, sc, X_D, ds);
+  SC(X_NUP) = nu_pen;
+  SC(X_DM) = gd - nu_pen * c1;
+  SC(X_PHI0) = s.th - mu * slog + nu_pen * c1;
+  SC(X_ALPHA) = apr; SC(X_ADU) = adu; SC(X_LS) = 0.0;
+  SC(X_STATE) = ST_TRIAL;
+}
+
+// ==============================================================================================
+// q_finish: results from each lane's current iterate buffer
+// ==============================================================================================
+__global__ __launch_bounds__(WAVE) void q_finish(const ascent_params *params, long batch, Geo g, double *ws,
+                                                 double *traj, double *tf_out, int *status_out,
+                                                 int *iters_out, double *blob) {
+  const long p = (long)blockIdx.x * WAVE + threadIdx.x;
+  if (p >= batch) return;
+  const QTile t_((gdbl *)ws + (size_t)blockIdx.x * g.tile_doubles());
+  gdbl *sc = scal_base(t_, g);
+  const Der d = derive(params[p]);
+  const int K = g.K, nt = K + 1;
+  const unsigned oc = buf_off(t_, (int)SC(X_CUR));
+  const Scal s = load_scal(t_, sc, X_S);
+  tf_out[p] = s.th;
+  status_out[p] = (int)SC(X_STATUS);
+  iters_out[p] = (int)SC(X_ITERS);
+  for (int k = 0; k < nt; k++) {
+    double z[7], u = 0.0, ax, ay;
+    if (k) {
+      const gdbl *sp = t_.st(k - 1);
+      ldo<7>(sp, Q_IT + O_Z, oc, z);
+      u = ROWO(sp, Q_IT + O_U, oc);
+      if (blob) {
+        const int kk = k - 1;
+        ASC_UNROLL
+        for (int i = 0; i < 7; i++) {
+          blob[(7L * kk + i) * batch + p] = z[i];
+          blob[(8L * K + 7L * kk + i) * batch + p] = ROWO(sp, Q_IT + O_L + i, oc);
+        }
+        blob[(7L * K + kk) * batch + p] = u;
+        ASC_UNROLL
+        for (int b = 0; b < 6; b++) blob[(15L * K + 6L * kk + b) * batch + p] = ROWO(sp, Q_IT + O_ZB + b, oc);
+      }
+    } else {
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) z[i] = 0.0;
+    }
+    if (traj) {
+      accel<0>(d, z[IX], z[IY], z[IA], z[IM], 0.0, 0.0, ax, ay, nullptr, nullptr);
+      const double v[10] = {z[IX], z[IY], z[IVX], z[IVY], ax, ay, z[IA], z[IW], u, z[IM]};
+      ASC_UNROLL
+      for (int f = 0; f < 10; f++) traj[((long)f * nt + k) * batch + p] = v[f];
+    }
+  }
+  if (blob) {
+    double *bs = blob + (21L * K) * batch + p;
+    bs[S_TH * batch] = s.th; bs[S_ZLT * batch] = s.zlt; bs[S_ZUT * batch] = s.zut; bs[S_S1 * batch] = s.s1;
+    bs[S_S2 * batch] = s.s2; bs[S_ZS1 * batch] = s.zs1; bs[S_ZS2 * batch] = s.zs2; bs[S_NU3 * batch] = s.nu3;
+    bs[S_NU1 * batch] = s.nu1; bs[S_NU2 * batch] = s.nu2;
+  }
+}
+
+}  // namespace
+
+// ==============================================================================================
+// host driver
+// ==============================================================================================
+namespace ascent {
+
+size_t pipeline_ws_bytes(int K, long batch) {
+  Geo g{K, (K + CHUNK - 1) / CHUNK};
+  const size_t tiles = (size_t)((batch + WAVE - 1) / WAVE);
+  return tiles * g.tile_doubles() * sizeof(double) + 64;   // + counters
+}
+
+#define PCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf(err, errlen, "%s: %s", #call, hipGetErrorString(e_)); return ASCENT_E_HIP; } } while (0)
+
+int pipeline_run(const ascent_params *dp, long batch, int K, double *ws, const double *dguess, int warm,
+                 int max_iter, double tol, double mu0, double *dtraj, double *dtf, int *dstatus, int *diters,
+                 double *dblob, hipStream_t stream, PipelineStats *stats, char *err, size_t errlen) {
+  Geo g{K, (K + CHUNK - 1) / CHUNK};
+  const unsigned tiles = (unsigned)((batch + WAVE - 1) / WAVE);
+  int *counters = (int *)((char *)ws + (size_t)tiles * g.tile_doubles() * sizeof(double));
+  int host_cnt[2];
+  const bool debug = getenv("ASCENT_DEBUG") != nullptr;
+  int launches = 0;
+  hipLaunchKernelGGL(q_init, dim3(tiles), dim3(WAVE), 0, stream, dp, batch, g, ws, dguess, warm, mu0);
+  PCHK(hipGetLastError());
+  // Each round advances every lane by one stage of its own state machine: a lane in its normal flow
+  // completes one interior-point iteration per round; a rejected line-search trial or a wrong-inertia
+  // factorisation costs that lane (only) one more round.  A lane needs at most max_iter+1 accepted trial
+  // points plus <= 40 rejected trials and ~50 refactorisations per iteration, so the loop terminates.
+  for (long round = 0;; round++) {
+    if (round > 100L * (max_iter + 2)) { snprintf(err, errlen, "pipeline did not terminate"); return ASCENT_E_HIP; }
+    hipLaunchKernelGGL(q_trial_eval, dim3(tiles, g.nch), dim3(WAVE), 0, stream, dp, batch, g, ws);
+    PCHK(hipMemsetAsync(counters, 0, 2 * sizeof(int), stream));
+    hipLaunchKernelGGL(q_decide_factor, dim3(tiles), dim3(WAVE), 0, stream, dp, batch, g, ws, max_iter, tol, counters);
+    PCHK(hipMemcpyAsync(host_cnt, counters, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+    launches += 2;
+    PCHK(hipStreamSynchronize(stream));
+    const int n_pending = host_cnt[0], n_factored = host_cnt[1];   // retrial/refactor lanes; lanes with a step to take
+    if (debug) fprintf(stderr, "[ascent pipeline] round %ld: pending %d, stepping %d\n", round, n_pending, n_factored);
+    if (n_pending == 0 && n_factored == 0) break;
+    if (n_factored > 0) {
+      hipLaunchKernelGGL(q_forward, dim3(tiles), dim3(WAVE), 0, stream, dp, batch, g, ws);
+      hipLaunchKernelGGL(q_local, dim3(tiles, g.nch), dim3(WAVE), 0, stream, dp, batch, g, ws);
+      hipLaunchKernelGGL(q_adjoint, dim3(tiles), dim3(WAVE), 0, stream, dp, batch, g, ws);
+      launches += 3;
+    }
+  }
+  hipLaunchKernelGGL(q_finish, dim3(tiles), dim3(WAVE), 0, stream, dp, batch, g, ws, dtraj, dtf, dstatus, diters,
+                     dblob);
+  PCHK(hipGetLastError());
+  if (stats) stats->launches = launches + 2;
+  return ASCENT_OK;
+}
+
+}  // namespace ascent

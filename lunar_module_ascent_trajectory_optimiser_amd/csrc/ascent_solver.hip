@@ -28,6 +28,8 @@
 
 #include "ascent.h"
 #include "ascent_device.hpp"
+#include "ascent_tile.hpp"
+#include "ascent_pipeline.hpp"
 
 using namespace ascent;
 
@@ -38,11 +40,8 @@ constexpr int R_Z = 0, R_U = 7, R_L = 8, R_ZB = 15;          // iterate: z[7] u 
 constexpr int R_DZ = 21, R_DU = 28, R_DL = 29, R_DZB = 36;   // step:    same order
 constexpr int R_G = 42, R_E = 50, R_H = 54, R_F = 64, R_C = 71, R_KA = 78, R_K0 = 85, R_ID = 88;
 constexpr int R_STAGE = 94;
-constexpr int WAVE = 64;
 
 __host__ __device__ inline size_t tile_doubles(int K) { return (size_t)K * R_STAGE * WAVE; }
-
-typedef __attribute__((address_space(1))) double gdbl;   // HBM (global address space) double
 
 struct W {  // one lane's view of its tile
   gdbl *tile;  // wave-uniform base of this wavefront's tile
@@ -50,90 +49,7 @@ struct W {  // one lane's view of its tile
   double h;
   Der d;
 };
-
-// A pointer / integer that is the same in all 64 lanes, moved to scalar registers so that the
-// compiler addresses HBM as  scalar base + lane  (global_load ... s[base:base+1]).
-ASC_DEV gdbl *uniform(gdbl *p) {
-  const unsigned long long v = (unsigned long long)p;
-  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v);
-  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
-  return (gdbl *)(((unsigned long long)hi << 32) | lo);
-}
-ASC_DEV int uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
-
-struct Tile {  // uniform tile base + this lane
-  gdbl *base;
-  unsigned lane;
-  ASC_DEV explicit Tile(const W &w) : base(uniform(w.tile)), lane(threadIdx.x) {}
-  ASC_DEV gdbl *st(int k) const { return base + (size_t)k * (R_STAGE * WAVE); }
-};
-#define ROW(p, r) (p)[(r) * WAVE + t_.lane]
-#define ASC_PASS __device__ __noinline__   // one register allocation per pass
-
-template <int N>
-ASC_DEV void ldn(const Tile &t_, const gdbl *p, int r0, double *v) {
-  ASC_UNROLL
-  for (int i = 0; i < N; i++) v[i] = ROW(p, r0 + i);
-}
-template <int N>
-ASC_DEV void stn(const Tile &t_, gdbl *p, int r0, const double *v) {
-  ASC_UNROLL
-  for (int i = 0; i < N; i++) ROW(p, r0 + i) = v[i];
-}
-template <int N>
-ASC_DEV void cpy(double *dst, const double *src) {
-  ASC_UNROLL
-  for (int i = 0; i < N; i++) dst[i] = src[i];
-}
-
-// scalars of the iterate / step kept in registers
-struct Scal {
-  double th, zlt, zut, s1, s2, zs1, zs2, nu3, nu1, nu2;
-};
-
-struct ErrParts {  // E(mu) = max(rd/sd, cinf, comp(mu)/sd), comp(mu) from the extreme complementarity products
-  double rd, cinf, pmin, pmax, sd;
-  ASC_DEV double err(double mu) const {
-    const double comp = fmax(fabs(pmax - mu), fabs(pmin - mu));
-    return fmax(fmax(rd / sd, cinf), comp / sd);
-  }
-};
-
-ASC_DEV double clipz(double zv, double dist, double mu) {
-  return fmin(fmax(zv, mu / (1e10 * dist)), 1e10 * mu / dist);
-}
-
-// ---------------------------------------------------------------------------------------------
-// Loop skeleton shared by all passes: the step records are double-buffered in registers (A, B);
-// while step k is being computed the loads of the next step are already in flight.  Unrolled by two
-// so that the buffers swap roles without register copies.
-// ---------------------------------------------------------------------------------------------
-#define ASC_SWEEP_BACKWARD(IN, LOAD, BODY)                 \
-  {                                                        \
-    IN bufA, bufB;                                         \
-    LOAD(K - 1, bufA);                                     \
-    int k = K - 1;                                         \
-    for (; k >= 1; k -= 2) {                               \
-      LOAD(k - 1, bufB);                                   \
-      BODY(bufA, k);                                       \
-      if (k >= 2) LOAD(k - 2, bufA);                       \
-      BODY(bufB, k - 1);                                   \
-    }                                                      \
-    if (k == 0) BODY(bufA, 0);                             \
-  }
-#define ASC_SWEEP_FORWARD(IN, LOAD, BODY)                  \
-  {                                                        \
-    IN bufA, bufB;                                         \
-    LOAD(0, bufA);                                         \
-    int k = 0;                                             \
-    for (; k + 1 < K; k += 2) {                            \
-      LOAD(k + 1, bufB);                                   \
-      BODY(bufA, k);                                       \
-      if (k + 2 < K) LOAD(k + 2, bufA);                    \
-      BODY(bufB, k + 1);                                   \
-    }                                                      \
-    if (k == K - 1) BODY(bufA, k);                         \
-  }
+using Tile = TileT<R_STAGE>;
 
 // ---------------------------------------------------------------------------------------------
 // pass UE: (optionally) accept the step  it += alpha*step  and evaluate the KKT error pieces of the
@@ -166,7 +82,7 @@ ASC_DEV void loadUE(const Tile &t_, int k, InUE &in) {
 template <bool UPDATE>
 ASC_PASS ErrParts pass_update_error(const W &w, const Scal &s, double alpha, double adu, double mu) {
   const Der &d = w.d;
-  const Tile t_(w);
+  const Tile t_(w.tile);
   const int K = uniform(w.K);
   const double hT = w.h * d.T, dt = hT * s.th;
   double rd = 0.0, cinf = 0.0, pmin = 1e300, pmax = -1e300, l1 = 0.0, zsum = 0.0, rth = 1.0;
@@ -277,7 +193,7 @@ ASC_DEV void loadB(const Tile &t_, int k, InB &in) {
 
 ASC_PASS int pass_backward(const W &w, const Scal &s, double mu, double dw, BorderOut &out) {
   const Der &d = w.d;
-  const Tile t_(w);
+  const Tile t_(w.tile);
   const int K = uniform(w.K);
   const double hT = w.h * d.T, dt = hT * s.th, be = dt * d.alpha;
   double P[28], p0[7], p1[7], p2[7];
@@ -418,10 +334,6 @@ ASC_PASS int pass_backward(const W &w, const Scal &s, double mu, double dw, Bord
 // pass F: forward substitution (primal step), primal fraction-to-boundary, barrier slope and the
 // barrier sum at the current iterate
 // ---------------------------------------------------------------------------------------------
-#define ASC_FTB(a, val, dv) do { const double dv_ = (dv); if (dv_ < 0.0) a = fmin(a, -tau * (val) / dv_); } while (0)
-// same test with the reciprocal of the distance at hand: alpha <= tau / (-dv/val)
-#define ASC_FTBR(amax_inv, ival, dv) amax_inv = fmax(amax_inv, -(dv) * (ival))
-
 struct InF {
   double G[8], E[4], cc[7], F[7], ka[7], k0[3], id[6], a, m, u;
 };
@@ -442,7 +354,7 @@ ASC_DEV void loadF(const Tile &t_, int k, InF &in) {
 ASC_PASS void pass_forward(const W &w, const Scal &s, double mu, double tau, double dth, double dnu3,
                            double &apr, double &gd, double &slog, double *dzK) {
   const Der &d = w.d;
-  const Tile t_(w);
+  const Tile t_(w.tile);
   const int K = uniform(w.K);
   const double hT = w.h * d.T, dt = hT * s.th, be = dt * d.alpha;
   double dzp[7];
@@ -504,7 +416,7 @@ ASC_PASS void pass_adjoint(const W &w, const Scal &s, double mu, double dw, doub
                            double dnu3, double sig1, double sig2, double rs1, double rs2, double &adu,
                            double &cl) {
   const Der &d = w.d;
-  const Tile t_(w);
+  const Tile t_(w.tile);
   const int K = uniform(w.K);
   const double hT = w.h * d.T, dt = hT * s.th;
   double dln[7], ln[7];
@@ -583,7 +495,7 @@ ASC_DEV void loadT(const Tile &t_, int k, InT &in) {
 
 ASC_PASS double pass_trial(const W &w, const Scal &s, const Scal &ds, double alpha, double mu, double nu_pen) {
   const Der &d = w.d;
-  const Tile t_(w);
+  const Tile t_(w.tile);
   const int K = uniform(w.K);
   const double th = s.th + alpha * ds.th, s1 = s.s1 + alpha * ds.s1, s2 = s.s2 + alpha * ds.s2;
   const double dt = w.h * d.T * th;
@@ -617,17 +529,10 @@ ASC_PASS double pass_trial(const W &w, const Scal &s, const Scal &ds, double alp
 // ---------------------------------------------------------------------------------------------
 // initial point
 // ---------------------------------------------------------------------------------------------
-ASC_DEV double push_in(double v, double lb, double ub) {
-  const double k1 = 1e-2;
-  const double pl = fmin(k1 * fmax(1.0, fabs(lb)), k1 * (ub - lb));
-  const double pu = fmin(k1 * fmax(1.0, fabs(ub)), k1 * (ub - lb));
-  return fmin(fmax(v, lb + pl), ub - pu);
-}
-
 // cold start: straight-line states toward a tangential insertion point, u = 0
 ASC_DEV void cold_guess(const W &w, Scal &s) {
   const Der &d = w.d;
-  const Tile t_(w);
+  const Tile t_(w.tile);
   const int K = uniform(w.K);
   const double tf0 = 0.9, dr = 0.166, aend = 0.5, vp = sqrt(d.vp2), dt = w.h * d.T * tf0;
   const double sdr = sin(dr), cdr = cos(dr);
@@ -646,7 +551,7 @@ ASC_DEV void cold_guess(const W &w, Scal &s) {
 // interior point + multipliers. mode 0/1: primal only (multipliers reset); 2: keep multipliers
 ASC_DEV void init_point(const W &w, Scal &s, int mode) {
   const Der &d = w.d;
-  const Tile t_(w);
+  const Tile t_(w.tile);
   const int K = uniform(w.K);
   for (int k = 0; k < K; k++) {
     gdbl *sp = t_.st(k);
@@ -690,7 +595,7 @@ ASC_DEV int newton_step(const W &w, const Scal &s, double mu, double dw, Scal &d
   pass_forward(w, s, mu, tau, bo.dth, bo.dnu3, apr, gd, slog, dzK);
   pass_adjoint(w, s, mu, dw, tau, bo.dth, bo.dnu3, bo.sig1, bo.sig2, bo.rs1, bo.rs2, adu, cl);
   double zK[7];
-  const Tile t_(w);
+  const Tile t_(w.tile);
   ldn<7>(t_, t_.st(w.K - 1), R_Z, zK);
   const Terminal tm = terminal_eval(d, zK);
   ds.th = bo.dth; ds.nu3 = bo.dnu3;
@@ -726,7 +631,7 @@ ASC_DEV W make_w(double *ws, int K, const ascent_params &prm) {
 // external blob rows ([row][batch], include/ascent.h) <-> step records
 ASC_DEV void blob_to_tile(const W &w, const double *blob, long batch, long p, int r_z, int r_u, int r_l,
                           int r_zb, Scal &s) {
-  const Tile t_(w);
+  const Tile t_(w.tile);
   const int K = uniform(w.K);
   for (int k = 0; k < K; k++) {
     gdbl *sp = t_.st(k);
@@ -747,7 +652,7 @@ ASC_DEV void blob_to_tile(const W &w, const double *blob, long batch, long p, in
 
 ASC_DEV void tile_to_blob(const W &w, double *blob, long batch, long p, int r_z, int r_u, int r_l, int r_zb,
                           const Scal &s) {
-  const Tile t_(w);
+  const Tile t_(w.tile);
   const int K = uniform(w.K);
   for (int k = 0; k < K; k++) {
     const gdbl *sp = t_.st(k);
@@ -853,7 +758,7 @@ __global__ __launch_bounds__(WAVE) void k_solve(const ascent_params *params, lon
   iters_out[p] = iters;
   if (blob_out) tile_to_blob(w, blob_out, batch, p, R_Z, R_U, R_L, R_ZB, s);
   if (traj) {
-    const Tile t_(w);
+    const Tile t_(w.tile);
     const int nt = K + 1;
     for (int k = 0; k < nt; k++) {
       double z[7], u = 0.0, ax, ay;
@@ -935,6 +840,17 @@ constexpr int MAX_DEV = 64;
 DeviceWs g_ws[MAX_DEV];
 std::mutex g_mu[MAX_DEV];
 
+// Which solver runs a batch: the split pipeline (ascent_pipeline.hip: node-parallel evaluation + thin
+// serial sweeps, best while the batch alone cannot fill the chip) or the fused one-lane-per-NLP kernel
+// (least HBM traffic and no host round trips, best for large batches).  ASCENT_PIPELINE=split|fused
+// overrides the batch-size rule.
+bool use_split_pipeline(int64_t batch) {
+  const char *e = getenv("ASCENT_PIPELINE");
+  if (e && !strcmp(e, "split")) return true;
+  if (e && !strcmp(e, "fused")) return false;
+  return batch <= 12288;   // measured crossover on MI355X, N=200 (scripts/batch_sweep.py)
+}
+
 // NLPs per wavefront (tile). 64 fills every lane; smaller values spread a small batch over more
 // wavefronts (and so more SIMDs) at the price of idle lanes.  Chosen per launch by lanes_per_tile().
 int lanes_per_tile(int64_t batch) {
@@ -998,7 +914,7 @@ int ascent_debug_profile(unsigned long long *out8, int reset) {
 }
 #endif
 
-int ascent_version(void) { return 101; }
+int ascent_version(void) { return 102; }
 
 int ascent_device_count(void) {
   int n = 0;
@@ -1042,7 +958,8 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
   const int K = o->n_nodes - 1, nt = o->n_nodes;
   const size_t rows = 21 * (size_t)K + NSC;
   const int lpt = lanes_per_tile(batch);
-  rc = ensure_ws(device_id, ws_bytes(K, batch, lpt));
+  const bool split = use_split_pipeline(batch);
+  rc = ensure_ws(device_id, split ? pipeline_ws_bytes(K, (long)batch) : ws_bytes(K, batch, lpt));
   if (rc) return rc;
   DeviceWs &w = g_ws[device_id];
   const double mu0 = o->mu_init > 0 ? o->mu_init : (o->warm_start ? 1e-4 : 0.1);
@@ -1071,9 +988,15 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
   }
   const unsigned grid = (unsigned)((batch + lpt - 1) / lpt);
   HIPCHK(hipEventRecord(w.ev0, stream));
-  hipLaunchKernelGGL(k_solve, dim3(grid), dim3(WAVE), 0, stream, dp, (long)batch, lpt, K, w.ws, dguess,
-                     (int)o->warm_start, (int)o->max_iter, o->tol, mu0, dtraj, dtf, dstatus, diters, dblob);
-  HIPCHK(hipGetLastError());
+  if (split) {
+    rc = pipeline_run(dp, (long)batch, K, w.ws, dguess, (int)o->warm_start, (int)o->max_iter, o->tol, mu0, dtraj,
+                      dtf, dstatus, diters, dblob, stream, nullptr, g_err, sizeof g_err);
+    if (rc) return rc;
+  } else {
+    hipLaunchKernelGGL(k_solve, dim3(grid), dim3(WAVE), 0, stream, dp, (long)batch, lpt, K, w.ws, dguess,
+                       (int)o->warm_start, (int)o->max_iter, o->tol, mu0, dtraj, dtf, dstatus, diters, dblob);
+    HIPCHK(hipGetLastError());
+  }
   HIPCHK(hipEventRecord(w.ev1, stream));
   w.launched = true;
   if (!ptr_is_device) {

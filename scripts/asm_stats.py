@@ -1,10 +1,10 @@
 """Developer tool: per-function instruction / register statistics of the gfx950 code object."""
 import os, re, subprocess, sys, tempfile
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "lunar_module_ascent_trajectory_optimiser_amd", "csrc", "ascent_solver.hip")
+src = os.path.join(ROOT, "lunar_module_ascent_trajectory_optimiser_amd", "csrc", os.environ.get("ASM_SRC", "ascent_solver.hip"))
 d = tempfile.mkdtemp()
 subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"),
-                "-save-temps", "-o", "x.so", src] + sys.argv[1:], cwd=d, check=True, stderr=subprocess.DEVNULL)
+                "-save-temps", "-c", "-o", "x.o", src] + sys.argv[1:], cwd=d, check=True, stderr=subprocess.DEVNULL)
 s = open(os.path.join(d, [f for f in os.listdir(d) if f.endswith("gfx950.s")][0])).read()
 if os.environ.get("KEEP_ASM"):
     open(os.environ["KEEP_ASM"], "w").write(s)

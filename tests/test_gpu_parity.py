@@ -104,6 +104,31 @@ def test_batch_sweep_matches_oracle(coracle):
     assert np.array_equal(r.iters, ref["iters"])
 
 
+def test_split_and_fused_paths_agree(coracle, monkeypatch):
+    """The two solver paths (split pipeline for small batches, fused one-lane-per-NLP kernel for large
+    ones; ASCENT_PIPELINE overrides the batch-size rule) run the same algorithm: same answers, same
+    iteration counts, both equal to the oracle."""
+    S = A.sweep_isp_drymass(10, 7)
+    ref = coracle.solve_batch(S, NT, 300, 1e-9)
+    out = {}
+    for mode in ("split", "fused"):
+        monkeypatch.setenv("ASCENT_PIPELINE", mode)
+        out[mode] = A.solve_batch(S, NT, tol=1e-9, want_blob=True)
+        assert np.all(out[mode].status == 0)
+        assert np.abs(out[mode].tf - ref["tf"]).max() <= 1e-9 * ref["tf"].max()
+        assert np.abs(np.moveaxis(out[mode].traj, 2, 0) - ref["traj"]).max() < 1e-7
+        assert np.array_equal(out[mode].iters, ref["iters"])
+    assert np.abs(out["split"].tf - out["fused"].tf).max() <= 1e-12
+    assert np.abs(out["split"].blob - out["fused"].blob).max() <= 1e-6 * np.abs(out["fused"].blob).max()
+    # warm start and max_iter through both paths
+    for mode in ("split", "fused"):
+        monkeypatch.setenv("ASCENT_PIPELINE", mode)
+        w = A.solve_batch(S, NT, tol=1e-9, guess=out["fused"].blob, warm_start=2, mu_init=1e-9)
+        assert np.all(w.status == 0) and w.iters.max() <= 8 and np.abs(w.tf - ref["tf"]).max() <= 1e-9
+        m = A.solve_batch(S[:5], NT, tol=1e-9, max_iter=4)
+        assert np.all(m.status == 1) and np.all(m.iters == 4)
+
+
 def test_ragged_batch_and_small_grids(coracle):
     """Batch sizes that are not multiples of the wave size, and other grid sizes."""
     for B, nt in ((1, 3), (3, 12), (65, 50), (130, 25)):
