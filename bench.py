@@ -56,12 +56,30 @@ def rank_params(batch: int, rank: int, world: int) -> np.ndarray:
     return A.sweep_isp_drymass(n, batch // n, base=base)       # 4096 -> the 64 x 64 grid of config 3
 
 
+def usable_cores() -> int:
+    """Host cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(float(quota) / float(period))))
+    except (OSError, ValueError):
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // per))
+        except (OSError, ValueError):
+            pass
+    return int(os.environ.get("ASCENT_CPU_THREADS", n))
+
+
 def cpu_baseline(params: np.ndarray, nt: int, tol: float, sample: int):
     """Times the plain-C oracle (oracle/ascent_oracle.c, kind "port") on all host cores."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import c_oracle
     c_oracle.build()
-    cores = len(os.sched_getaffinity(0))
+    cores = usable_cores()
     idx = np.linspace(0, len(params) - 1, sample).astype(int)
     S = np.ascontiguousarray(params[idx])
     chunks = np.array_split(np.arange(sample), cores * 4)
@@ -85,6 +103,7 @@ def main():
     ap.add_argument("--tol", type=float, default=1e-9)
     ap.add_argument("--cpu-sample", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a CPU rehearsal of the gather)")
     args = ap.parse_args()
 
     import torch
@@ -98,23 +117,28 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the HIP path has no CPU fallback)")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
+    cdev = dev if args.backend == "nccl" else torch.device("cpu")      # where collectives run
 
     B = args.batch_per_gpu
     P = rank_params(B, rank, world)
     P_t = torch.from_numpy(P).to(dev)                      # inputs resident in HBM before timing
     out = {}
-    gathered = [torch.empty((B, 3), dtype=torch.float64, device=dev) for _ in range(world)] if (dist and rank == 0) else None
+    gathered = [torch.empty((B, 3), dtype=torch.float64, device=cdev) for _ in range(world)] if (dist and rank == 0) else None
 
     def step():
         A.solve_batch_torch(P_t, NT, tol=args.tol, want_traj=True, out=out)
         if dist:                                           # the job's only collective: result gather
-            pack = torch.stack([out["tf"], out["status"].double(), out["iters"].double()], dim=1)
+            pack = torch.stack([out["tf"], out["status"].double(), out["iters"].double()], dim=1).to(cdev)
             dist.gather(pack, gathered, dst=0)
 
     def barrier():
@@ -133,7 +157,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     if dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
@@ -142,7 +166,7 @@ def main():
     conv_local = int((status == 0).sum())
     conv_total = conv_local
     if dist:
-        t = torch.tensor([conv_local], dtype=torch.float64, device=dev)
+        t = torch.tensor([conv_local], dtype=torch.float64, device=cdev)
         dist.all_reduce(t)
         conv_total = int(t.item())
     if rank == 0:
