@@ -40,7 +40,8 @@ constexpr int Q_KA = 120, Q_K0 = 127, Q_R = 130;
 constexpr int Q_STAGE = 137;
 // Q_SC rows: R0 ru0 bza bzm bu (2 spare)
 constexpr int CHUNK = 8;                // collocation steps per wavefront of q_trial_eval
-constexpr int NPART = 9;                // rd cinf pmin pmax l1 zsum rth c1 sl
+constexpr int NPART = 15;               // rd cinf pmin pmax l1 zsum rth c1 sl + (c1, sl) at alpha/2, /4, /8
+constexpr int NLAD = 3;                 // extra step sizes whose merit value q_trial_eval computes on the side
 
 // ---- per-lane scalar rows (after the step records of the tile) -----------------------------------
 enum {
@@ -49,8 +50,9 @@ enum {
   X_T = X_S + 10,            // 10: trial scalars
   X_D = X_T + 10,            // 10: step scalars
   X_MU = X_D + 10, X_NUP, X_DW, X_DWL, X_ALPHA, X_ADU, X_PHI0, X_DM, X_C1, X_SL,
-  X_DTH, X_DNU3, X_SIG1, X_SIG2, X_RS1, X_RS2, X_CUR, X_RTH,
-  NSCAL
+  X_DTH, X_DNU3, X_SIG1, X_SIG2, X_RS1, X_RS2, X_CUR, X_RTH, X_ROUNDS,
+  X_LAD,                     // 6: merit pieces (c1, sl) of the trial ladder alpha/2, alpha/4, alpha/8
+  NSCAL = X_LAD + 6
 };
 enum { ST_TRIAL = 0, ST_FACTOR = 1, ST_FACTORED = 2, ST_DONE = 3 };
 
@@ -210,14 +212,24 @@ __global__ __launch_bounds__(WAVE) void q_trial_eval(const ascent_params *params
   const unsigned oc = buf_off(t_, cur), on = buf_off(t_, 1 - cur);   // current / trial iterate rows
   const double mlo = mu * 1e-10, mhi = mu * 1e10;
 
-  double z[7], ln[7];
+  // Backtracking ladder: besides the full evaluation at alpha, the l1-merit pieces at alpha/2, alpha/4
+  // and alpha/8 are computed on the side (this kernel is HBM-bound, the arithmetic is free), so that a
+  // rejected trial can jump straight to the first acceptable halving instead of one halving per round.
+  const bool ladder = !first;
+  double al[NLAD], dtl[NLAD], lc1[NLAD], lsl[NLAD];
+  ASC_UNROLL
+  for (int j = 0; j < NLAD; j++) {
+    al[j] = alpha * (0.5 / (double)(1 << j));
+    dtl[j] = hT * (s.th + al[j] * ds.th);
+    lc1[j] = 0.0; lsl[j] = 0.0;
+  }
+  double z[7], ln[7], zc[7], zd[7];   // zc, zd: current state and its step at the step being processed
   {   // trial state of the chunk's last step, trial multipliers of the step after it
     const gdbl *sp = t_.st(k_hi);
-    double dz[7];
-    ldo<7>(sp, Q_IT + O_Z, oc, z);
-    ldn<7>(t_, sp, Q_ST + O_Z, dz);
+    ldo<7>(sp, Q_IT + O_Z, oc, zc);
+    ldn<7>(t_, sp, Q_ST + O_Z, zd);
     ASC_UNROLL
-    for (int i = 0; i < 7; i++) z[i] += alpha * dz[i];
+    for (int i = 0; i < 7; i++) z[i] = zc[i] + alpha * zd[i];
     if (k_hi + 1 < K) {
       const gdbl *sn = t_.st(k_hi + 1);
       double dl[7];
@@ -233,12 +245,13 @@ __global__ __launch_bounds__(WAVE) void q_trial_eval(const ascent_params *params
   double rd = 0.0, cinf = 0.0, pmin = 1e300, pmax = -1e300, l1 = 0.0, zsum = 0.0, rth = 0.0, c1 = 0.0, sl = 0.0;
   for (int k = k_hi; k >= k_lo; k--) {
     gdbl *sp = t_.st(k);
-    double zp[7], l[7], zb[6], tmp7[7], tmp6[6];
+    double zp[7], l[7], zb[6], tmp7[7], tmp6[6], zpc[7];
     ldo<7>(sp, Q_IT + O_L, oc, l);
     ldn<7>(t_, sp, Q_ST + O_L, tmp7);
     ASC_UNROLL
     for (int i = 0; i < 7; i++) l[i] += alpha * tmp7[i];
-    const double u = ROWO(sp, Q_IT + O_U, oc) + alpha * ROW(sp, Q_ST + O_U);
+    const double uc = ROWO(sp, Q_IT + O_U, oc), ud = ROW(sp, Q_ST + O_U);
+    const double u = uc + alpha * ud;
     ldo<6>(sp, Q_IT + O_ZB, oc, zb);
     ldn<6>(t_, sp, Q_ST + O_ZB, tmp6);
     const double a = z[IA], m = z[IM];
@@ -251,13 +264,35 @@ __global__ __launch_bounds__(WAVE) void q_trial_eval(const ascent_params *params
     }
     if (k > 0) {
       const gdbl *spp = t_.st(k - 1);
-      ldo<7>(spp, Q_IT + O_Z, oc, zp);
+      ldo<7>(spp, Q_IT + O_Z, oc, zpc);
       ldn<7>(t_, spp, Q_ST + O_Z, tmp7);
       ASC_UNROLL
-      for (int i = 0; i < 7; i++) zp[i] += alpha * tmp7[i];
+      for (int i = 0; i < 7; i++) zp[i] = zpc[i] + alpha * tmp7[i];
     } else {
       ASC_UNROLL
-      for (int i = 0; i < 7; i++) zp[i] = 0.0;
+      for (int i = 0; i < 7; i++) { zp[i] = 0.0; zpc[i] = 0.0; tmp7[i] = 0.0; }
+    }
+    if (ladder) {   // merit pieces at the shorter steps (values only: no derivatives, nothing stored)
+      ASC_UNROLL
+      for (int j = 0; j < NLAD; j++) {
+        double zj[7], Fj[7], axj, ayj;
+        ASC_UNROLL
+        for (int i = 0; i < 7; i++) zj[i] = zc[i] + al[j] * zd[i];
+        const double uj = uc + al[j] * ud;
+        accel<0>(d, zj[IX], zj[IY], zj[IA], zj[IM], 0.0, 0.0, axj, ayj, nullptr, nullptr);
+        rhs_f(d, zj, uj, axj, ayj, Fj);
+        ASC_UNROLL
+        for (int i = 0; i < 7; i++) lc1[j] += fabs(zj[i] - (zpc[i] + al[j] * tmp7[i]) - dtl[j] * Fj[i]);
+        const double pa = zj[IA] * (d.aub - zj[IA]), pm = zj[IM] * (1.0 - zj[IM]), pu = (uj + 1.0) * (1.0 - uj);
+        lsl[j] += (pa > 0.0 && pm > 0.0 && pu > 0.0) ? log(pa * pm * pu) : NAN;
+        if (k == K - 1) {
+          const Terminal tj = terminal_eval(d, zj);
+          const double thj = s.th + al[j] * ds.th, s1j = s.s1 + al[j] * ds.s1, s2j = s.s2 + al[j] * ds.s2;
+          lc1[j] += fabs(tj.e3) + fabs(tj.g1 - s1j) + fabs(tj.g2 - s2j);
+          const double ps = ((thj - d.tlb) * (d.tub - thj)) * (s1j * s2j);
+          lsl[j] += ps > 0.0 ? log(ps) : NAN;
+        }
+      }
     }
     // the trial iterate of this step
     sto<7>(sp, Q_IT + O_Z, on, z);
@@ -326,10 +361,14 @@ __global__ __launch_bounds__(WAVE) void q_trial_eval(const ascent_params *params
     sl += (pa > 0.0 && pm > 0.0 && pu > 0.0) ? log(pa * pm * pu) : NAN;
     cpy<7>(ln, l);
     cpy<7>(z, zp);
+    cpy<7>(zc, zpc);
+    cpy<7>(zd, tmp7);
   }
   gdbl *pp = part_base(t_, g, chunk);
   ROW(pp, 0) = rd; ROW(pp, 1) = cinf; ROW(pp, 2) = pmin; ROW(pp, 3) = pmax; ROW(pp, 4) = l1;
   ROW(pp, 5) = zsum; ROW(pp, 6) = rth; ROW(pp, 7) = c1; ROW(pp, 8) = sl;
+  ASC_UNROLL
+  for (int j = 0; j < NLAD; j++) { ROW(pp, 9 + 2 * j) = lc1[j]; ROW(pp, 10 + 2 * j) = lsl[j]; }
 }
 
 // ==============================================================================================
@@ -365,6 +404,7 @@ __global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *par
   gdbl *sc = scal_base(t_, g);
   int state = (int)SC(X_STATE);
   if (state == ST_DONE) return;
+  SC(X_ROUNDS) = SC(X_ROUNDS) + 1.0;
   const Der d = derive(params[p]);
   const int K = g.K;
   double mu = SC(X_MU);
@@ -384,12 +424,28 @@ __global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *par
       const double alpha = SC(X_ALPHA), phi0 = SC(X_PHI0), Dm = SC(X_DM);
       const double phit = st.th - mu * sl + nu_pen * c1;
       if (!(isfinite(phit) && phit <= phi0 + 1e-8 * alpha * Dm + 2.220446049250313e-15 * fabs(phi0))) {
-        const int ls = (int)SC(X_LS) + 1;
+        // rejected: walk the halving sequence alpha/2, alpha/4, ... through the ladder values computed on the
+        // side; the first acceptable one (or, failing that, alpha/16) is what gets evaluated in the next round
+        int ls = (int)SC(X_LS) + 1;
+        double an = 0.5 * alpha;
+        ASC_UNROLL
+        for (int j = 0; j < NLAD; j++) {
+          double c1j = 0.0, slj = 0.0;
+          for (int c = g.nch - 1; c >= 0; c--) {
+            const gdbl *pp = part_base(t_, g, c);
+            c1j += ROW(pp, 9 + 2 * j); slj += ROW(pp, 10 + 2 * j);
+          }
+          const double thj = SC(X_S + S_TH) + an * SC(X_D + S_TH);
+          const double phij = thj - mu * slj + nu_pen * c1j;
+          if (isfinite(phij) && phij <= phi0 + 1e-8 * an * Dm + 2.220446049250313e-15 * fabs(phi0)) break;
+          if (ls >= 40) break;
+          an *= 0.5; ls++;
+        }
         SC(X_LS) = ls;
         if (ls >= 40) {
           SC(X_STATUS) = ASCENT_LINESEARCH_FAILED; SC(X_STATE) = ST_DONE;
         } else {
-          SC(X_ALPHA) = 0.5 * alpha;       // stays in ST_TRIAL: re-evaluated in the next round
+          SC(X_ALPHA) = an;                // stays in ST_TRIAL: evaluated in full in the next round
           atomicAdd(&counters[0], 1);
         }
         return;
@@ -555,6 +611,7 @@ __global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *par
     } else {
       SC(X_DW) = ndw; SC(X_STATE) = ST_FACTOR;
       atomicAdd(&counters[0], 1);
+      atomicAdd(&counters[2], 1);
     }
   }
 }
@@ -791,7 +848,7 @@ __global__ __launch_bounds__(WAVE) void q_adjoint(const ascent_params *params, l
 // ==============================================================================================
 __global__ __launch_bounds__(WAVE) void q_finish(const ascent_params *params, long batch, Geo g, double *ws,
                                                  double *traj, double *tf_out, int *status_out,
-                                                 int *iters_out, double *blob) {
+                                                 int *iters_out, double *blob, int rounds_instead_of_iters) {
   const long p = (long)blockIdx.x * WAVE + threadIdx.x;
   if (p >= batch) return;
   const QTile t_((gdbl *)ws + (size_t)blockIdx.x * g.tile_doubles());
@@ -802,7 +859,7 @@ __global__ __launch_bounds__(WAVE) void q_finish(const ascent_params *params, lo
   const Scal s = load_scal(t_, sc, X_S);
   tf_out[p] = s.th;
   status_out[p] = (int)SC(X_STATUS);
-  iters_out[p] = (int)SC(X_ITERS);
+  iters_out[p] = rounds_instead_of_iters ? (int)SC(X_ROUNDS) : (int)SC(X_ITERS);
   for (int k = 0; k < nt; k++) {
     double z[7], u = 0.0, ax, ay;
     if (k) {
@@ -860,7 +917,7 @@ int pipeline_run(const ascent_params *dp, long batch, int K, double *ws, const d
   Geo g{K, (K + CHUNK - 1) / CHUNK};
   const unsigned tiles = (unsigned)((batch + WAVE - 1) / WAVE);
   int *counters = (int *)((char *)ws + (size_t)tiles * g.tile_doubles() * sizeof(double));
-  int host_cnt[2];
+  int host_cnt[3];
   const bool debug = getenv("ASCENT_DEBUG") != nullptr;
   int launches = 0;
   hipLaunchKernelGGL(q_init, dim3(tiles), dim3(WAVE), 0, stream, dp, batch, g, ws, dguess, warm, mu0);
@@ -872,13 +929,13 @@ int pipeline_run(const ascent_params *dp, long batch, int K, double *ws, const d
   for (long round = 0;; round++) {
     if (round > 100L * (max_iter + 2)) { snprintf(err, errlen, "pipeline did not terminate"); return ASCENT_E_HIP; }
     hipLaunchKernelGGL(q_trial_eval, dim3(tiles, g.nch), dim3(WAVE), 0, stream, dp, batch, g, ws);
-    PCHK(hipMemsetAsync(counters, 0, 2 * sizeof(int), stream));
+    PCHK(hipMemsetAsync(counters, 0, 3 * sizeof(int), stream));
     hipLaunchKernelGGL(q_decide_factor, dim3(tiles), dim3(WAVE), 0, stream, dp, batch, g, ws, max_iter, tol, counters);
-    PCHK(hipMemcpyAsync(host_cnt, counters, 2 * sizeof(int), hipMemcpyDeviceToHost, stream));
+    PCHK(hipMemcpyAsync(host_cnt, counters, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
     launches += 2;
     PCHK(hipStreamSynchronize(stream));
     const int n_pending = host_cnt[0], n_factored = host_cnt[1];   // retrial/refactor lanes; lanes with a step to take
-    if (debug) fprintf(stderr, "[ascent pipeline] round %ld: pending %d, stepping %d\n", round, n_pending, n_factored);
+    if (debug) fprintf(stderr, "[ascent pipeline] round %ld: pending %d (refactor %d), stepping %d\n", round, n_pending, host_cnt[2], n_factored);
     if (n_pending == 0 && n_factored == 0) break;
     if (n_factored > 0) {
       hipLaunchKernelGGL(q_forward, dim3(tiles), dim3(WAVE), 0, stream, dp, batch, g, ws);
@@ -888,7 +945,7 @@ int pipeline_run(const ascent_params *dp, long batch, int K, double *ws, const d
     }
   }
   hipLaunchKernelGGL(q_finish, dim3(tiles), dim3(WAVE), 0, stream, dp, batch, g, ws, dtraj, dtf, dstatus, diters,
-                     dblob);
+                     dblob, getenv("ASCENT_DEBUG_ROUNDS") != nullptr);
   PCHK(hipGetLastError());
   if (stats) stats->launches = launches + 2;
   return ASCENT_OK;
