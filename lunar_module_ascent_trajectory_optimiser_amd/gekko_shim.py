@@ -1,0 +1,388 @@
+"""A GEKKO-compatible problem-definition surface for the lunar-ascent model family.
+
+The reference script (/root/reference/Launch_Optimiser.py) is written against the third-party GEKKO
+modelling API and hands its model to APMonitor/IPOPT at `m.solve(disp=True)` (line 177).  This module
+offers the calls that script makes (`GEKKO()`, `m.time`, `m.options.*`,
+`m.Const/FV/Var/MV/Param`, `m.Equation`, `var.dt()`, `m.cos/m.sin`, `m.fix`, `m.Minimize`, `m.solve`,
+`.value`, `.STATUS/.DCOST/...`) and, at `solve()`, maps the declared model onto the built-in ascent NLP
+of libascent (include/ascent.h) instead of shipping it to a general NLP solver.
+
+It is not a general modelling language.  `solve()` *recognises* the ascent model family:
+  1. variables are found by the names the reference gives them (`name='y'`, `'ydot'`, ... :83-96);
+  2. the physical constants are read from the named `m.Const`s (:55-63, 74, 107-108) and the plain
+     Python numbers baked into the equations (final_time, mflow, the angular-acceleration scale, the
+     target speed and radius) are recovered by probing the recorded expression trees;
+  3. every declared equation is then evaluated numerically at random points and compared with the
+     built-in model for those parameters.  Any mismatch raises `ModelNotRecognised` -- nothing is
+     silently approximated.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from .params import AscentParams
+
+__all__ = ["GEKKO", "ModelNotRecognised"]
+
+
+class ModelNotRecognised(NotImplementedError):
+    pass
+
+
+# ----------------------------------------------------------------------------------------------
+# expression trees
+# ----------------------------------------------------------------------------------------------
+def _wrap(v):
+    return v if isinstance(v, Expr) else Num(float(v))
+
+
+class Expr:
+    """A recorded arithmetic expression; evaluates numerically on an environment {leaf: value}."""
+    op = None
+
+    def __init__(self, op, *args):
+        self.op, self.args = op, args
+
+    # arithmetic
+    def __add__(self, o): return Expr("+", self, _wrap(o))
+    def __radd__(self, o): return Expr("+", _wrap(o), self)
+    def __sub__(self, o): return Expr("-", self, _wrap(o))
+    def __rsub__(self, o): return Expr("-", _wrap(o), self)
+    def __mul__(self, o): return Expr("*", self, _wrap(o))
+    def __rmul__(self, o): return Expr("*", _wrap(o), self)
+    def __truediv__(self, o): return Expr("/", self, _wrap(o))
+    def __rtruediv__(self, o): return Expr("/", _wrap(o), self)
+    def __pow__(self, o): return Expr("**", self, _wrap(o))
+    def __rpow__(self, o): return Expr("**", _wrap(o), self)
+    def __neg__(self): return Expr("neg", self)
+    def __pos__(self): return self
+    # relations produce equation records
+    def __eq__(self, o): return Relation(self, _wrap(o), "==")
+    def __ge__(self, o): return Relation(self, _wrap(o), ">=")
+    def __le__(self, o): return Relation(self, _wrap(o), "<=")
+    __hash__ = object.__hash__
+
+    def eval(self, env):
+        a = [x.eval(env) for x in self.args]
+        op = self.op
+        if op == "+": return a[0] + a[1]
+        if op == "-": return a[0] - a[1]
+        if op == "*": return a[0] * a[1]
+        if op == "/": return a[0] / a[1]
+        if op == "**": return a[0] ** a[1]
+        if op == "neg": return -a[0]
+        if op == "cos": return np.cos(a[0])
+        if op == "sin": return np.sin(a[0])
+        raise ModelNotRecognised(f"operator {op!r} is not part of the ascent model family")
+
+    def leaves(self, out=None):
+        out = set() if out is None else out
+        for x in self.args:
+            x.leaves(out)
+        return out
+
+
+class Num(Expr):
+    def __init__(self, v):
+        self.v = v
+        self.op, self.args = "num", ()
+
+    def eval(self, env):
+        return self.v
+
+
+class Leaf(Expr):
+    """Var / MV / FV / Param: a named unknown (or time-varying datum) of the model."""
+    kind = "var"
+
+    def __init__(self, name=None, value=None, lb=None, ub=None):
+        self.op, self.args = "leaf", ()
+        self.name, self.lb, self.ub = name, lb, ub
+        self.value = value if value is not None else 0
+        self.STATUS = 0
+        self.DCOST = 0.0
+        self.fixed = {}            # pos -> val  (m.fix)
+
+    def eval(self, env):
+        return env[self]
+
+    def leaves(self, out=None):
+        out = set() if out is None else out
+        out.add(self)
+        return out
+
+    def dt(self):
+        return Derivative(self)
+
+    def __repr__(self):
+        return f"<{self.kind} {self.name}>"
+
+
+class Derivative(Expr):
+    def __init__(self, var):
+        self.var = var
+        self.op, self.args = "dt", ()
+
+    def eval(self, env):
+        raise ModelNotRecognised("a time derivative may only appear alone on one side of an equation")
+
+
+class Relation:
+    def __init__(self, lhs, rhs, rel):
+        self.lhs, self.rhs, self.rel = lhs, rhs, rel
+
+    def __bool__(self):
+        raise TypeError("a model relation has no truth value; pass it to m.Equation")
+
+
+class Const(float):
+    """m.Const: behaves as a plain number (so `np.full(nt, Rfmin+R0+1)` works, Launch_Optimiser.py:158)
+    but remembers its name for the parameter extraction."""
+    def __new__(cls, value, name=None):
+        o = super().__new__(cls, value)
+        o.name = name
+        return o
+
+
+class _Options:
+    """m.options: any attribute may be set; the ones that matter are checked at solve()."""
+    def __init__(self):
+        self.__dict__.update(NODES=2, SOLVER=3, IMODE=6, MAX_ITER=300, MV_TYPE=0, OTOL=1e-6, RTOL=1e-6,
+                             DIAGLEVEL=0, COLDSTART=0)
+
+
+# ----------------------------------------------------------------------------------------------
+# the model object
+# ----------------------------------------------------------------------------------------------
+DEFAULT_SOLVER = None      # None = the HIP library (solver.solve_batch); tests may set a stand-in
+
+ROLE_NAMES = ("x", "y", "xdot", "ydot", "xdoubledot", "ydoubledot", "angle", "angledot", "angledoubledot", "mass")
+
+
+class GEKKO:
+    """Drop-in for `gekko.GEKKO` restricted to the ascent model family (see module docstring).
+
+    `solver` (keyword, not part of GEKKO) lets tests inject a different batch solver; by default the
+    HIP library is used and a missing GPU is an error, never a silent CPU fallback."""
+
+    def __init__(self, remote=False, server=None, name=None, solver=None):
+        self.time = np.array([0.0, 1.0])
+        self.options = _Options()
+        self._consts, self._leaves, self._equations, self._objective = {}, [], [], None
+        self._solver = solver if solver is not None else DEFAULT_SOLVER
+        self.path = None
+        self.result = None
+
+    # -- declarations ------------------------------------------------------------------------------
+    def Const(self, value=0, name=None):
+        c = Const(value, name)
+        if name is not None:
+            self._consts[name] = float(value)
+        self._consts.setdefault("__unnamed__", [])
+        if name is None:
+            self._consts["__unnamed__"].append(float(value))
+        return c
+
+    def _leaf(self, kind, name, value, lb, ub):
+        v = Leaf(name, value, lb, ub)
+        v.kind = kind
+        self._leaves.append(v)
+        return v
+
+    def Var(self, value=None, lb=None, ub=None, integer=False, fixed_initial=True, name=None):
+        return self._leaf("var", name, value, lb, ub)
+
+    def SV(self, *a, **k): return self.Var(*a, **k)
+    def CV(self, *a, **k): return self.Var(*a, **k)
+
+    def MV(self, value=None, lb=None, ub=None, integer=False, fixed_initial=True, name=None):
+        return self._leaf("mv", name, value, lb, ub)
+
+    def FV(self, value=None, lb=None, ub=None, integer=False, fixed_initial=True, name=None):
+        return self._leaf("fv", name, value, lb, ub)
+
+    def Param(self, value=None, name=None):
+        p = self._leaf("param", name, value, None, None)
+        return p
+
+    def Equation(self, rel):
+        if not isinstance(rel, Relation):
+            raise TypeError("m.Equation expects a relation built with ==, >= or <=")
+        self._equations.append(rel)
+        return rel
+
+    def Equations(self, rels):
+        return [self.Equation(r) for r in rels]
+
+    def fix(self, var, pos=None, val=None):
+        var.fixed[pos] = val
+
+    def Minimize(self, e): self._objective = ("min", _wrap(e))
+    def Obj(self, e): self.Minimize(e)
+    def Maximize(self, e): self._objective = ("max", _wrap(e))
+
+    def cos(self, e): return Expr("cos", _wrap(e))
+    def sin(self, e): return Expr("sin", _wrap(e))
+    def sqrt(self, e): return _wrap(e) ** 0.5
+
+    # -- model recognition ---------------------------------------------------------------------------
+    def _role(self, name):
+        hits = [v for v in self._leaves if v.name == name]
+        if len(hits) != 1:
+            raise ModelNotRecognised(f"expected exactly one variable named {name!r} (found {len(hits)})")
+        return hits[0]
+
+    def _extract(self):
+        """Recover AscentParams from the declared model, then verify every equation numerically."""
+        o = self.options
+        if int(o.IMODE) != 6:
+            raise ModelNotRecognised("only IMODE=6 (simultaneous dynamic optimisation) is supported")
+        if int(o.NODES) != 2:
+            raise ModelNotRecognised("only NODES=2 (two-point collocation = backward Euler) is supported in this release")
+        nt = len(self.time)
+        if nt < 3 or not np.allclose(self.time, np.linspace(0.0, 1.0, nt)):
+            raise ModelNotRecognised("m.time must be np.linspace(0, 1, nt)")
+        R = {n: self._role(n) for n in ROLE_NAMES}
+        if R["angledoubledot"].kind != "mv":
+            raise ModelNotRecognised("the v1 formulation (angle itself is the MV) is not available on the GPU path yet")
+        fvs = [v for v in self._leaves if v.kind == "fv"]
+        if len(fvs) != 1 or self._objective is None or self._objective[0] != "min" or self._objective[1] is not fvs[0]:
+            raise ModelNotRecognised("the objective must be m.Minimize(tf) with tf the single FV")
+        tf = fvs[0]
+        if not tf.STATUS:
+            raise ModelNotRecognised("tf.STATUS must be 1 (free final time)")
+        params = [v for v in self._leaves if v.kind == "param"]
+        C = self._consts
+        try:
+            G, M, R0, Ft, M0 = C["G"], C["M"], C["R0"], C["Ft"], C["M0"]
+            S, ms = C["distance Scale"], C["mass Scale"]
+        except KeyError as e:
+            raise ModelNotRecognised(f"named constant {e} missing (Launch_Optimiser.py:55-63,107-108)") from None
+
+        # split the equations
+        ode, alg, ineq, eqc = {}, {}, [], []
+        for r in self._equations:
+            if isinstance(r.lhs, Derivative) and r.rel == "==":
+                ode[r.lhs.var] = r.rhs
+            elif isinstance(r.rhs, Derivative) and r.rel == "==":
+                ode[r.rhs.var] = r.lhs
+            elif r.rel == "==" and (r.lhs is R["xdoubledot"] or r.lhs is R["ydoubledot"]):
+                alg[r.lhs] = r.rhs
+            elif r.rel == ">=":
+                ineq.append(r)
+            elif r.rel == "==":
+                eqc.append(r)
+            else:
+                raise ModelNotRecognised("unsupported relation in the model")
+        states = ("x", "y", "xdot", "ydot", "angle", "angledot", "mass")
+        if {id(v) for v in ode} != {id(R[n]) for n in states} or {id(v) for v in alg} != {id(R["xdoubledot"]), id(R["ydoubledot"])}:
+            raise ModelNotRecognised("expected 7 differential equations and the two acceleration definitions")
+        if len(ineq) != 2 or len(eqc) != 1 or len(params) != 2:
+            raise ModelNotRecognised("expected the three masked terminal constraints (two >=, one ==) and two mask Params")
+
+        def env0(**kw):
+            e = {v: 0.0 for v in self._leaves}
+            e[tf] = 1.0
+            for k, val in kw.items():
+                e[R[k] if k in R else k] = val
+            return e
+
+        # plain-number constants recovered by probing the linear ODE right-hand sides (tf = 1)
+        T = float(ode[R["y"]].eval(env0(ydot=1.0)))                              # final_time, :38,114
+        alpha = float(ode[R["angledot"]].eval(env0(angledoubledot=1.0))) / T       # :109,121
+        mrate = float(ode[R["mass"]].eval(env0())) / T                            # mflow, :65,123
+        # terminal masks: which Param is which is decided by their last entries (:158-168)
+        pv = {p: np.asarray(p.value, dtype=float) for p in params}
+        for p, a in pv.items():
+            if a.shape != (nt,):
+                raise ModelNotRecognised("mask Params must have one entry per time point")
+        rad = [p for p, a in pv.items() if a[-1] == 0.0 and np.all(a[:-1] > 0)]
+        vel = [p for p, a in pv.items() if a[-1] == 1.0 and np.all(a[:-1] == 0)]
+        if len(rad) != 1 or len(vel) != 1:
+            raise ModelNotRecognised("terminal mask Params do not have the 0/1 last-node pattern of Launch_Optimiser.py:158-168")
+        rad, vel = rad[0], vel[0]
+        # speed constraint: (xdot^2+ydot^2) >= c * final_velocity  -> c = (periapsis_v/Scalar)^2
+        rs = [r for r in ineq if vel in (r.lhs.leaves() | r.rhs.leaves())]
+        rr = [r for r in ineq if rad in (r.lhs.leaves() | r.rhs.leaves())]
+        if len(rs) != 1 or len(rr) != 1:
+            raise ModelNotRecognised("could not tell the radius and the speed constraint apart")
+        e1 = env0(); e1[vel] = 1.0
+        vp2 = float(rs[0].rhs.eval(e1) - rs[0].lhs.eval(e1))          # lhs = 0 at zero velocity
+        GM = G * M
+        r_avg = GM / (vp2 * S * S) - R0                                # :72,75
+        r_peri = S                                                     # :73,107 (Scalar = Rfmin)
+        r_apo = 2.0 * r_avg - r_peri
+        P = AscentParams(G=G, M=M, R0=R0, Ft=Ft, M0=M0, mdot=mrate * ms, fuel_mass=ms, mass_scalar=ms,
+                         ang_acc_max=3.0 * alpha, r_peri=r_peri, r_apo=r_apo, T_scale=T,
+                         angle_ub=R["angle"].ub, tf_lb=tf.lb, tf_ub=tf.ub, dcost=float(R["angledoubledot"].DCOST or 0.0))
+        # bounds, initial conditions
+        if (R["mass"].lb, R["mass"].ub) != (0, 1) or (R["angledoubledot"].lb, R["angledoubledot"].ub) != (-1, 1) \
+                or R["angle"].lb != 0 or R["angle"].ub is None or tf.lb is None or tf.ub is None:
+            raise ModelNotRecognised("bounds differ from the model family (mass in [0,1], u in [-1,1], angle in [0,ub], tf in [lb,ub])")
+        for n in ("y", "x", "ydot", "xdot", "angle", "mass"):
+            if R[n].fixed.get(0) != 0:
+                raise ModelNotRecognised(f"initial condition m.fix({n}, pos=0, val=0) missing (Launch_Optimiser.py:145-151)")
+        self._verify(P, R, tf, ode, alg, rr[0], rs[0], eqc[0], rad, vel)
+        return P, R, tf
+
+    def _verify(self, P, R, tf, ode, alg, rr, rs, eq3, rad, vel):
+        """Every declared equation against the built-in model at random points (relative 1e-9)."""
+        rng = np.random.default_rng(20251226)
+        S, GM = P.r_peri, P.G * P.M
+        for _ in range(6):
+            v = dict(x=rng.uniform(-17, 0), y=rng.uniform(-1, 1), xdot=rng.uniform(-0.1, 0), ydot=rng.uniform(-0.02, 0.02),
+                     angle=rng.uniform(0, 1), angledot=rng.uniform(-1, 1), angledoubledot=rng.uniform(-1, 1),
+                     mass=rng.uniform(0, 1), xdoubledot=rng.uniform(-1, 1), ydoubledot=rng.uniform(-1, 1))
+            tfv = rng.uniform(0.5, 1.0)
+            env = {leaf: 0.0 for leaf in self._leaves}
+            env.update({R[k]: val for k, val in v.items()})
+            env[tf] = tfv
+            X, Y = S * v["x"], S * v["y"] + P.R0
+            Rr = math.hypot(X, Y)
+            mp = P.M0 - P.mass_scalar * v["mass"]
+            c, s = math.cos(3 * v["angle"]), math.sin(3 * v["angle"])
+            ydd = (P.Ft / (mp * Rr) * (Y * c + X * s) - Y * GM / Rr ** 3) / S          # :127-130
+            xdd = (P.Ft / (mp * Rr) * (X * c - Y * s) - X * GM / Rr ** 3) / S          # :133-136
+            T = P.T_scale
+            want = {R["y"]: tfv * T * v["ydot"], R["ydot"]: tfv * T * v["ydoubledot"], R["x"]: tfv * T * v["xdot"],
+                    R["xdot"]: tfv * T * v["xdoubledot"], R["angle"]: tfv * T * v["angledot"],
+                    R["angledot"]: tfv * T * v["angledoubledot"] * P.ang_acc_max / 3.0,
+                    R["mass"]: tfv * T * P.mdot / P.fuel_mass}
+            checks = [(float(ode[k].eval(env)), w, f"d{k.name}/dt") for k, w in want.items()]
+            checks += [(float(alg[R["ydoubledot"]].eval(env)), ydd, "ydoubledot"),
+                       (float(alg[R["xdoubledot"]].eval(env)), xdd, "xdoubledot")]
+            # terminal constraints with the masks switched to their last-node values (:161,169,173)
+            env[rad], env[vel] = 0.0, 1.0
+            checks += [(float(rr.lhs.eval(env) - rr.rhs.eval(env)), math.hypot(v["x"], v["y"] + P.R0 / S) - (P.R0 + S) / S, "radius constraint"),
+                       (float(rs.lhs.eval(env) - rs.rhs.eval(env)), v["xdot"] ** 2 + v["ydot"] ** 2 - (P.periapsis_v / S) ** 2, "speed constraint"),
+                       (float(eq3.lhs.eval(env) - eq3.rhs.eval(env)) / S ** 2, (v["y"] + P.R0 / S) * v["ydot"] + v["x"] * v["xdot"], "r.v constraint")]
+            for got, wnt, what in checks:
+                if not abs(got - wnt) <= 1e-9 * max(1.0, abs(wnt)):
+                    raise ModelNotRecognised(f"{what} differs from the built-in ascent model ({got} vs {wnt})")
+
+    # -- solve -----------------------------------------------------------------------------------------
+    def solve(self, disp=True, debug=0, GUI=False, **kw):
+        P, R, tf = self._extract()
+        nt = len(self.time)
+        solver = self._solver
+        if solver is None:
+            from .solver import solve_batch as solver
+        max_iter = int(min(max(int(self.options.MAX_ITER), 1), 3000))
+        res = solver(P, nt=nt, tol=1e-9, max_iter=max_iter)
+        self.result = res
+        ok = int(res.status[0]) == 0
+        if disp:
+            print(" ----------------------------------------------------------------")
+            print(" libascent (MI355X) interior point: %d node ascent NLP, backward Euler (NODES=2)" % nt)
+            print(" iterations: %d   status: %s   objective tf: %.12g" % (int(res.iters[0]), "converged" if ok else f"FAILED ({int(res.status[0])})", float(res.tf[0])))
+            print(" ----------------------------------------------------------------")
+        if not ok:
+            raise Exception("@error: Solution Not Found (libascent status %d)" % int(res.status[0]))   # GEKKO raises a bare Exception too
+        for name in ROLE_NAMES:
+            R[name].value = [float(v) for v in res.field(name)[:, 0]]
+        tf.value = [float(res.tf[0])] * nt
+        self.options.APPSTATUS, self.options.SOLVESTATUS, self.options.OBJFCNVAL = 1, 1, float(res.tf[0])
+        self.options.ITERATIONS = int(res.iters[0])
+        return self
