@@ -24,6 +24,7 @@ struct TileT {  // uniform tile base + this lane; step records of STAGE_ROWS row
   gdbl *base;
   unsigned lane;
   ASC_DEV explicit TileT(gdbl *tile) : base(uniform(tile)), lane(threadIdx.x) {}
+  ASC_DEV TileT(gdbl *tile, unsigned lane_) : base(uniform(tile)), lane(lane_) {}
   ASC_DEV gdbl *st(int k) const { return base + (size_t)k * (STAGE_ROWS * WAVE); }
 };
 #define ROW(p, r) (p)[(r) * WAVE + t_.lane]
