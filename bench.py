@@ -103,6 +103,7 @@ def main():
     ap.add_argument("--tol", type=float, default=1e-9)
     ap.add_argument("--cpu-sample", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-continuation", action="store_true", help="skip the secondary warm-start (continuation) measurement")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a CPU rehearsal of the gather)")
     args = ap.parse_args()
 
@@ -208,6 +209,26 @@ def main():
                          "FP64-issue/latency bound: see DESIGN.md section 5"),
             },
         }
+        if world == 1 and not args.no_continuation:
+            # Secondary, differently-defined number (never `value`): the same sweep under a continuation policy --
+            # every NLP warm-started (primal-dual, mu0 = 1e-6) from the solution of the nominal Apollo-11 problem.
+            nom = A.solve_batch(A.AscentParams(tf_ub=float(P[0, 14])), NT, tol=args.tol, want_blob=True)
+            g_t = torch.from_numpy(np.ascontiguousarray(np.repeat(nom.blob, B, axis=1))).to(dev)
+            wout = {}
+            A.solve_batch_torch(P_t, NT, tol=args.tol, guess_t=g_t, warm_start=2, mu_init=1e-6, want_traj=True, out=wout, sync=True)
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                A.solve_batch_torch(P_t, NT, tol=args.tol, guess_t=g_t, warm_start=2, mu_init=1e-6, want_traj=True, out=wout)
+            torch.cuda.synchronize(dev)
+            wdt = (time.perf_counter() - t1) / args.steps
+            wit = wout["iters"].cpu().numpy()
+            wok = int((wout["status"].cpu().numpy() == 0).sum())
+            line["continuation"] = {
+                "value": wok / wdt, "unit": "NLPs/s", "ms_per_step": wdt * 1e3, "converged": wok,
+                "iterations_min_mean_max": [int(wit.min()), float(wit.mean()), int(wit.max())],
+                "max_abs_tf_diff_vs_cold": float((wout["tf"] - out["tf"]).abs().max().item()),
+                "policy": "primal-dual warm start of every NLP from the nominal Apollo-11 solution, mu0=1e-6; not the headline value",
+            }
         if world == 1 and not args.no_cpu_baseline:
             cb, idx, res = cpu_baseline(P, NT, args.tol, min(args.cpu_sample, B))
             tf_cpu = np.concatenate([r["tf"] for r in res])

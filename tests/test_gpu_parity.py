@@ -185,6 +185,19 @@ def test_config3_full_size_properties():
     assert np.array_equal(r2.tf, r.tf[perm]) and np.array_equal(r2.iters, r.iters[perm])
 
 
+def test_mesh_refinement_matches_oracle_and_richardson(coracle):
+    """Other grid sizes through the same path: N = 400 against the oracle, and first-order convergence of the
+    backward-Euler scheme: 2*t_f(400) - t_f(200) = 435.217 s, the mesh-converged value
+    the trapezoid probe gave (435.227 s)."""
+    P = A.AscentParams()
+    r2, r4 = A.solve_batch(P, 200, tol=1e-9), A.solve_batch(P, 400, tol=1e-9)
+    ref = coracle.solve_batch(P.as_row()[None], 400, 300, 1e-9)
+    assert r4.status[0] == 0 and ref["status"][0] == 0
+    assert abs(r4.tf[0] - ref["tf"][0]) <= 1e-9 * ref["tf"][0] and r4.iters[0] == ref["iters"][0]
+    assert abs(r4.final_time()[0] - 434.6222) < 2e-3              # survey probe: 434.62229 s
+    assert abs(2 * r4.final_time()[0] - r2.final_time()[0] - 435.217) < 0.02
+
+
 def test_non_converged_problems_are_flagged():
     """max_iter too small -> status max_iter, never silently 'converged'."""
     r = A.solve_batch(A.sweep_isp_drymass(2, 2), NT, tol=1e-9, max_iter=5)
