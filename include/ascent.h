@@ -48,7 +48,8 @@ typedef struct ascent_params {
 
 typedef struct ascent_opts {
   int32_t n_nodes;     /* :20  nt, number of grid points (tau_k = k/(nt-1), :21)         */
-  int32_t scheme;      /* 0 = NODES=2 two-point collocation = backward Euler (:25)      */
+  int32_t scheme;      /* 0 = NODES=2 two-point collocation = backward Euler (:25);
+                          1 = trapezoid, control held over the step (not a reference scheme) */
   int32_t max_iter;    /* :28  interior-point iteration cap                              */
   int32_t warm_start;  /* 0 = built-in cold-start guess, 1 = primal part of `guess`,
                           2 = full primal-dual `guess` (multipliers kept)                */

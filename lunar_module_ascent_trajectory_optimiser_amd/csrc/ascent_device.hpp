@@ -241,6 +241,45 @@ ASC_DEV void fzt_lambda(const double *G, const double *l, double *fl) {
   fl[IM] = G[3] * l[IVX] + G[7] * l[IVY];
 }
 
+// (d f/d z) v
+ASC_DEV void fz_mul(const double *G, const double *v, double *o) {
+  o[IX] = v[IVX];
+  o[IY] = v[IVY];
+  o[IVX] = G[0] * v[IX] + G[1] * v[IY] + G[2] * v[IA] + G[3] * v[IM];
+  o[IVY] = G[4] * v[IX] + G[5] * v[IY] + G[6] * v[IA] + G[7] * v[IM];
+  o[IA] = v[IW];
+  o[IW] = 0.0;
+  o[IM] = 0.0;
+}
+
+// Trapezoid scheme only: N <- Abar' N Abar with Abar = I + c * df/dz (packed symmetric N).  Abar has the
+// x<->xdot, y<->ydot two-cycles, so it is not a product of the elementary congruences used for A^-1; the
+// product is formed as T = N*Abar (sparse column combinations), then the upper triangle of Abar'*T.
+ASC_DEV void congruence_abar(double *N, const double *G, double c) {
+  double T[7][7];
+  ASC_UNROLL
+  for (int i = 0; i < 7; i++) {
+    const double nx = N[sid(i, IX)], ny = N[sid(i, IY)], nvx = N[sid(i, IVX)], nvy = N[sid(i, IVY)];
+    T[i][IX] = nx + c * (G[0] * nvx + G[4] * nvy);
+    T[i][IY] = ny + c * (G[1] * nvx + G[5] * nvy);
+    T[i][IVX] = nvx + c * nx;
+    T[i][IVY] = nvy + c * ny;
+    T[i][IA] = N[sid(i, IA)] + c * (G[2] * nvx + G[6] * nvy);
+    T[i][IW] = N[sid(i, IW)] + c * N[sid(i, IA)];
+    T[i][IM] = N[sid(i, IM)] + c * (G[3] * nvx + G[7] * nvy);
+  }
+  ASC_UNROLL
+  for (int j = 0; j < 7; j++) {
+    if (j >= IX) N[sid(IX, j)] = T[IX][j] + c * (G[0] * T[IVX][j] + G[4] * T[IVY][j]);
+    if (j >= IY) N[sid(IY, j)] = T[IY][j] + c * (G[1] * T[IVX][j] + G[5] * T[IVY][j]);
+    if (j >= IVX) N[sid(IVX, j)] = T[IVX][j] + c * T[IX][j];
+    if (j >= IVY) N[sid(IVY, j)] = T[IVY][j] + c * T[IY][j];
+    if (j >= IA) N[sid(IA, j)] = T[IA][j] + c * (G[2] * T[IVX][j] + G[6] * T[IVY][j]);
+    if (j >= IW) N[sid(IW, j)] = T[IW][j] + c * T[IA][j];
+    if (j >= IM) N[sid(IM, j)] = T[IM][j] + c * (G[3] * T[IVX][j] + G[7] * T[IVY][j]);
+  }
+}
+
 // right-hand side f(z,u) of the scaled ODEs without the tf*T factor (Launch_Optimiser.py:114-123)
 ASC_DEV void rhs_f(const Der &d, const double *z, double u, double ax, double ay, double *F) {
   F[IX] = z[IVX];

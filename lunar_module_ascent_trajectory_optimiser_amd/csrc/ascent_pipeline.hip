@@ -193,6 +193,11 @@ ASC_DEV unsigned buf_off(const QTile &t_, int buf) { return t_.lane + (unsigned)
 // ==============================================================================================
 // q_trial_eval: one wavefront = 64 NLPs x CHUNK consecutive steps
 // ==============================================================================================
+// SCHEME 0: backward Euler (the reference's NODES=2).  SCHEME 1: trapezoid with the control held over the
+// step, z_k - z_{k-1} - dt/2 [f(z_k,u_k) + f(z_{k-1},u_k)]: node k then enters steps k and k+1 with weight
+// 1/2 each, so every occurrence of lambda_k in the node's dual residual / Hessian weights becomes
+// lambda_k + lambda_{k+1} with step constant cs = dt/2, and the stored step function is the mean of the two f's.
+template <int SCHEME>
 __global__ __launch_bounds__(WAVE) void q_trial_eval(const ascent_params *params, long batch, Geo g,
                                                      double *ws) {
   const long p = (long)blockIdx.x * WAVE + threadIdx.x;
@@ -208,6 +213,7 @@ __global__ __launch_bounds__(WAVE) void q_trial_eval(const ascent_params *params
   const Scal s = load_scal(t_, sc, X_S), ds = load_scal(t_, sc, X_D);
   const Scal st = trial_scal(d, s, ds, alpha, adu, mu, first);
   const double hT = (1.0 / K) * d.T, dt = hT * st.th, be = dt * d.alpha;
+  const double cs = SCHEME == 1 ? 0.5 * dt : dt, hTc = SCHEME == 1 ? 0.5 * hT : hT;
   const int cur = (int)SC(X_CUR);
   const unsigned oc = buf_off(t_, cur), on = buf_off(t_, 1 - cur);   // current / trial iterate rows
   const double mlo = mu * 1e-10, mhi = mu * 1e10;
@@ -281,8 +287,18 @@ __global__ __launch_bounds__(WAVE) void q_trial_eval(const ascent_params *params
         const double uj = uc + al[j] * ud;
         accel<0>(d, zj[IX], zj[IY], zj[IA], zj[IM], 0.0, 0.0, axj, ayj, nullptr, nullptr);
         rhs_f(d, zj, uj, axj, ayj, Fj);
+        double zpj[7];
         ASC_UNROLL
-        for (int i = 0; i < 7; i++) lc1[j] += fabs(zj[i] - (zpc[i] + al[j] * tmp7[i]) - dtl[j] * Fj[i]);
+        for (int i = 0; i < 7; i++) zpj[i] = zpc[i] + al[j] * tmp7[i];
+        if (SCHEME == 1) {
+          double Fb[7];
+          accel<0>(d, zpj[IX], zpj[IY], zpj[IA], zpj[IM], 0.0, 0.0, axj, ayj, nullptr, nullptr);
+          rhs_f(d, zpj, uj, axj, ayj, Fb);
+          ASC_UNROLL
+          for (int i = 0; i < 7; i++) Fj[i] = 0.5 * (Fj[i] + Fb[i]);
+        }
+        ASC_UNROLL
+        for (int i = 0; i < 7; i++) lc1[j] += fabs(zj[i] - zpj[i] - dtl[j] * Fj[i]);
         const double pa = zj[IA] * (d.aub - zj[IA]), pm = zj[IM] * (1.0 - zj[IM]), pu = (uj + 1.0) * (1.0 - uj);
         lsl[j] += (pa > 0.0 && pm > 0.0 && pu > 0.0) ? log(pa * pm * pu) : NAN;
         if (k == K - 1) {
@@ -300,16 +316,25 @@ __global__ __launch_bounds__(WAVE) void q_trial_eval(const ascent_params *params
     sto<7>(sp, Q_IT + O_L, on, l);
     sto<6>(sp, Q_IT + O_ZB, on, zb);
     // node evaluation (Launch_Optimiser.py:114-136) with Jacobian and Lagrangian-Hessian blocks
-    double G[8], E[4], H[10], F[7], fl[7], ax, ay;
-    accel<2>(d, z[IX], z[IY], z[IA], z[IM], -dt * l[IVX], -dt * l[IVY], ax, ay, G, H);
+    double G[8], E[4], H[10], F[7], fl[7], lt[7], ax, ay;
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) lt[i] = SCHEME == 1 ? l[i] + ln[i] : l[i];
+    accel<2>(d, z[IX], z[IY], z[IA], z[IM], -cs * lt[IVX], -cs * lt[IVY], ax, ay, G, H);
     rhs_f(d, z, u, ax, ay, F);
-    implicit_block(G, dt, E);
-    fzt_lambda(G, l, fl);
+    if (SCHEME == 1) {       // second evaluation point of the step: f(z_{k-1}, u_k)
+      double Fb[7], axp, ayp;
+      accel<0>(d, zp[IX], zp[IY], zp[IA], zp[IM], 0.0, 0.0, axp, ayp, nullptr, nullptr);
+      rhs_f(d, zp, u, axp, ayp, Fb);
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) F[i] = 0.5 * (F[i] + Fb[i]);
+    }
+    implicit_block(G, cs, E);
+    fzt_lambda(G, lt, fl);
     double rz[7], gt[7], cc[7];
     ASC_UNROLL
     for (int i = 0; i < 7; i++) {
-      rz[i] = l[i] - dt * fl[i] - ln[i];
-      gt[i] = -hT * fl[i];
+      rz[i] = l[i] - cs * fl[i] - ln[i];
+      gt[i] = -hTc * fl[i];
       cc[i] = z[i] - zp[i] - dt * F[i];
       c1 += fabs(cc[i]);
       cinf = fmax(cinf, fabs(cc[i]));
@@ -396,6 +421,7 @@ ASC_DEV void loadQV(const QTile &t_, int k, InQV &in) {
   in.ru0 = ROW(sp, Q_SC + 1); in.bza = ROW(sp, Q_SC + 2); in.bzm = ROW(sp, Q_SC + 3); in.bu = ROW(sp, Q_SC + 4);
 }
 
+template <int SCHEME>
 __global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *params, long batch, Geo g,
                                                         double *ws, int max_iter, double tol, int *counters) {
   const long p = (long)blockIdx.x * WAVE + threadIdx.x;
@@ -490,6 +516,7 @@ __global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *par
   const Scal s = load_scal(t_, sc, X_S);
   const double dw = SC(X_DW);
   const double hT = (1.0 / K) * d.T, dt = hT * s.th, be = dt * d.alpha, ith = rcp(s.th);
+  const double cs = SCHEME == 1 ? 0.5 * dt : dt;
   double P[28], p0[7], p1[7], p2[7];
   ASC_UNROLL
   for (int i = 0; i < 28; i++) P[i] = 0.0;
@@ -509,13 +536,26 @@ __global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *par
     InQV cv;
     loadQV(t_, k, cv);                    // in flight while the congruence runs
     const double *G = cm.G, *E = cm.E, *H = cm.H;
+    if (SCHEME == 1 && k < K - 1) {   // pull the value function of step k+1 back through Abar = I + cs*F_z(z_k)
+      congruence_abar(P, G, cs);
+      double t_[7];
+      fzt_lambda(G, p0, t_);
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) p0[i] += cs * t_[i];
+      fzt_lambda(G, p1, t_);
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) p1[i] += cs * t_[i];
+      fzt_lambda(G, p2, t_);
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) p2[i] += cs * t_[i];
+    }
     P[sid(IX, IX)] += H[0]; P[sid(IX, IY)] += H[1]; P[sid(IX, IA)] += H[2]; P[sid(IX, IM)] += H[3];
     P[sid(IY, IY)] += H[4]; P[sid(IY, IA)] += H[5]; P[sid(IY, IM)] += H[6];
     P[sid(IA, IA)] += H[7]; P[sid(IA, IM)] += H[8]; P[sid(IM, IM)] += H[9];
     ASC_UNROLL
     for (int i = 0; i < 7; i++) P[sid(i, i)] += dw;
     if (k == K - 1) terminal_hessian(P, tm, s.nu3, s.nu1, s.nu2, sig1, sig2);
-    congruence(P, G, E, dt);
+    congruence(P, G, E, cs);
     const double D = cm.R0 + dw + be * be * P[sid(IW, IW)];
     if (!(D > 0.0)) bad = 1;
     const double iD = rcp(D);
@@ -545,7 +585,7 @@ __global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *par
     double n[7], nt[7], q0[7], q1[7], rc1[7], Prc[7], k00, k01, k02;
     ASC_UNROLL
     for (int i = 0; i < 7; i++) n[i] = -rz[i] + p0[i];
-    solveAT(G, E, dt, n, nt);
+    solveAT(G, E, cs, n, nt);
     k00 = (be * nt[IW] - ru) * iD;
     ASC_UNROLL
     for (int i = 0; i < 7; i++) { q0[i] = nt[i] - mw[i] * k00; n[i] = -cc[i]; }
@@ -554,7 +594,7 @@ __global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *par
     for (int i = 0; i < 7; i++) p0[i] = q0[i] - Prc[i];
     ASC_UNROLL
     for (int i = 0; i < 7; i++) n[i] = -cv.gt[i] + p1[i];
-    solveAT(G, E, dt, n, nt);
+    solveAT(G, E, cs, n, nt);
     k01 = (be * nt[IW] - gu) * iD;
     ASC_UNROLL
     for (int i = 0; i < 7; i++) { q1[i] = nt[i] - mw[i] * k01; rc1[i] = hT * cv.F[i]; }
@@ -563,7 +603,7 @@ __global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *par
     for (int i = 0; i < 7; i++) p1[i] = q1[i] - Prc[i];
     cpy<7>(n, p2);
     if (k == K - 1) { n[IX] -= tm.e3g[0]; n[IY] -= tm.e3g[1]; n[IVX] -= tm.e3g[2]; n[IVY] -= tm.e3g[3]; }
-    solveAT(G, E, dt, n, nt);
+    solveAT(G, E, cs, n, nt);
     k02 = be * nt[IW] * iD;
     ASC_UNROLL
     for (int i = 0; i < 7; i++) p2[i] = nt[i] - mw[i] * k02;
@@ -632,6 +672,7 @@ ASC_DEV void loadQF(const QTile &t_, int k, InQF &in) {
   ldn<3>(t_, sp, Q_K0, in.k0);
 }
 
+template <int SCHEME>
 __global__ __launch_bounds__(WAVE) void q_forward(const ascent_params *params, long batch, Geo g, double *ws) {
   const long p = (long)blockIdx.x * WAVE + threadIdx.x;
   if (p >= batch) return;
@@ -642,23 +683,33 @@ __global__ __launch_bounds__(WAVE) void q_forward(const ascent_params *params, l
   const int K = g.K;
   const double th = SC(X_S + S_TH), dth = SC(X_DTH), dnu3 = SC(X_DNU3);
   const double hT = (1.0 / K) * d.T, dt = hT * th, be = dt * d.alpha;
-  double dzp[7];
+  const double cs = SCHEME == 1 ? 0.5 * dt : dt;
+  double dzp[7], Gp[8];          // previous step's dz; for the trapezoid also its Jacobian block (Abar_k = I + cs*F_z(z_{k-1}))
   ASC_UNROLL
   for (int i = 0; i < 7; i++) dzp[i] = 0.0;
+  ASC_UNROLL
+  for (int i = 0; i < 8; i++) Gp[i] = 0.0;
   auto body = [&](InQF &cur_, int k) __attribute__((always_inline)) {
     gdbl *sp = t_.st(k);
     double xi[7], dz[7];
     double du = cur_.k0[0] + cur_.k0[1] * dth + cur_.k0[2] * dnu3;
+    if (SCHEME == 1) {
+      double t2_[7];
+      fz_mul(Gp, dzp, t2_);
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) dzp[i] += cs * t2_[i];
+    }
     ASC_UNROLL
     for (int i = 0; i < 7; i++) {
       xi[i] = dzp[i] - cur_.cc[i] + hT * cur_.F[i] * dth;
       du -= cur_.ka[i] * xi[i];
     }
     xi[IW] += be * du;
-    solveA(cur_.G, cur_.E, dt, xi, dz);
+    solveA(cur_.G, cur_.E, cs, xi, dz);
     stn<7>(t_, sp, Q_ST + O_Z, dz);
     ROW(sp, Q_ST + O_U) = du;
     cpy<7>(dzp, dz);
+    if (SCHEME == 1) cpy<8>(Gp, cur_.G);
   };
 #define LD_(k_, buf_) loadQF(t_, k_, buf_)
   ASC_SWEEP_FORWARD4(InQF, LD_, body)
@@ -764,6 +815,7 @@ ASC_DEV void loadQA(const QTile &t_, int k, InQA &in) {
   ldn<7>(t_, sp, Q_C, in.cc);
 }
 
+template <int SCHEME>
 __global__ __launch_bounds__(WAVE) void q_adjoint(const ascent_params *params, long batch, Geo g, double *ws) {
   const long p = (long)blockIdx.x * WAVE + threadIdx.x;
   if (p >= batch) return;
@@ -777,6 +829,7 @@ __global__ __launch_bounds__(WAVE) void q_adjoint(const ascent_params *params, l
   const double mu = SC(X_MU), dth = SC(X_DTH), dnu3 = SC(X_DNU3);
   const double sig1 = SC(X_SIG1), sig2 = SC(X_SIG2), rs1 = SC(X_RS1), rs2 = SC(X_RS2);
   const double hT = (1.0 / K) * d.T, dt = hT * s.th;
+  const double cs = SCHEME == 1 ? 0.5 * dt : dt;
   const double tau = fmax(0.99, 1.0 - mu);
   double dln[7];
   ASC_UNROLL
@@ -787,7 +840,13 @@ __global__ __launch_bounds__(WAVE) void q_adjoint(const ascent_params *params, l
     double r[7], dl[7];
     ASC_UNROLL
     for (int i = 0; i < 7; i++) r[i] = cur_.r[i] + dln[i];
-    solveAT(cur_.G, cur_.E, dt, r, dl);
+    if (SCHEME == 1) {           // Abar_{k+1}' dlambda_{k+1} = dlambda_{k+1} + cs * F_z(z_k)' dlambda_{k+1}
+      double t2_[7];
+      fzt_lambda(cur_.G, dln, t2_);
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) r[i] += cs * t2_[i];
+    }
+    solveAT(cur_.G, cur_.E, cs, r, dl);
     stn<7>(t_, sp, Q_ST + O_L, dl);
     ASC_UNROLL
     for (int i = 0; i < 7; i++) cl += cur_.cc[i] * dl[i];
@@ -911,7 +970,7 @@ size_t pipeline_ws_bytes(int K, long batch) {
 
 #define PCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf(err, errlen, "%s: %s", #call, hipGetErrorString(e_)); return ASCENT_E_HIP; } } while (0)
 
-int pipeline_run(const ascent_params *dp, long batch, int K, double *ws, const double *dguess, int warm,
+int pipeline_run(const ascent_params *dp, long batch, int K, int scheme, double *ws, const double *dguess, int warm,
                  int max_iter, double tol, double mu0, double *dtraj, double *dtf, int *dstatus, int *diters,
                  double *dblob, hipStream_t stream, PipelineStats *stats, char *err, size_t errlen) {
   Geo g{K, (K + CHUNK - 1) / CHUNK};
@@ -928,9 +987,11 @@ int pipeline_run(const ascent_params *dp, long batch, int K, double *ws, const d
   // points plus <= 40 rejected trials and ~50 refactorisations per iteration, so the loop terminates.
   for (long round = 0;; round++) {
     if (round > 100L * (max_iter + 2)) { snprintf(err, errlen, "pipeline did not terminate"); return ASCENT_E_HIP; }
-    hipLaunchKernelGGL(q_trial_eval, dim3(tiles, g.nch), dim3(WAVE), 0, stream, dp, batch, g, ws);
+    if (scheme == 1) hipLaunchKernelGGL(q_trial_eval<1>, dim3(tiles, g.nch), dim3(WAVE), 0, stream, dp, batch, g, ws);
+    else hipLaunchKernelGGL(q_trial_eval<0>, dim3(tiles, g.nch), dim3(WAVE), 0, stream, dp, batch, g, ws);
     PCHK(hipMemsetAsync(counters, 0, 3 * sizeof(int), stream));
-    hipLaunchKernelGGL(q_decide_factor, dim3(tiles), dim3(WAVE), 0, stream, dp, batch, g, ws, max_iter, tol, counters);
+    if (scheme == 1) hipLaunchKernelGGL(q_decide_factor<1>, dim3(tiles), dim3(WAVE), 0, stream, dp, batch, g, ws, max_iter, tol, counters);
+    else hipLaunchKernelGGL(q_decide_factor<0>, dim3(tiles), dim3(WAVE), 0, stream, dp, batch, g, ws, max_iter, tol, counters);
     PCHK(hipMemcpyAsync(host_cnt, counters, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
     launches += 2;
     PCHK(hipStreamSynchronize(stream));
@@ -938,9 +999,11 @@ int pipeline_run(const ascent_params *dp, long batch, int K, double *ws, const d
     if (debug) fprintf(stderr, "[ascent pipeline] round %ld: pending %d (refactor %d), stepping %d\n", round, n_pending, host_cnt[2], n_factored);
     if (n_pending == 0 && n_factored == 0) break;
     if (n_factored > 0) {
-      hipLaunchKernelGGL(q_forward, dim3(tiles), dim3(WAVE), 0, stream, dp, batch, g, ws);
+      if (scheme == 1) hipLaunchKernelGGL(q_forward<1>, dim3(tiles), dim3(WAVE), 0, stream, dp, batch, g, ws);
+      else hipLaunchKernelGGL(q_forward<0>, dim3(tiles), dim3(WAVE), 0, stream, dp, batch, g, ws);
       hipLaunchKernelGGL(q_local, dim3(tiles, g.nch), dim3(WAVE), 0, stream, dp, batch, g, ws);
-      hipLaunchKernelGGL(q_adjoint, dim3(tiles), dim3(WAVE), 0, stream, dp, batch, g, ws);
+      if (scheme == 1) hipLaunchKernelGGL(q_adjoint<1>, dim3(tiles), dim3(WAVE), 0, stream, dp, batch, g, ws);
+      else hipLaunchKernelGGL(q_adjoint<0>, dim3(tiles), dim3(WAVE), 0, stream, dp, batch, g, ws);
       launches += 3;
     }
   }

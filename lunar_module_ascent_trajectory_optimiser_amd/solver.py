@@ -19,8 +19,12 @@ def blob_rows(nt: int) -> int:
     return 21 * (nt - 1) + 10
 
 
-def _opts(nt, max_iter, tol, warm_start, mu_init):
-    return _lib.AscentOptsC(n_nodes=nt, scheme=0, max_iter=max_iter, warm_start=warm_start, tol=tol,
+SCHEMES = {"backward_euler": 0, "trapezoid": 1}
+
+
+def _opts(nt, max_iter, tol, warm_start, mu_init, scheme=0):
+    scheme = SCHEMES.get(scheme, scheme)
+    return _lib.AscentOptsC(n_nodes=nt, scheme=int(scheme), max_iter=max_iter, warm_start=warm_start, tol=tol,
                             mu_init=mu_init)
 
 
@@ -74,9 +78,10 @@ class BatchResult:
 
 def solve_batch(params, nt: int = 200, tol: float = 1e-9, max_iter: int = 300, guess: np.ndarray | None = None,
                 warm_start: int | None = None, mu_init: float = 0.0, device: int = 0, want_traj: bool = True,
-                want_blob: bool = False) -> BatchResult:
+                want_blob: bool = False, scheme=0) -> BatchResult:
     """Solve a batch of ascent NLPs on one GPU.  params: AscentParams | list | (batch,16) array.
-    guess: (21K+10, batch) blob, with warm_start 1 (primal only) or 2 (primal-dual)."""
+    guess: (21K+10, batch) blob, with warm_start 1 (primal only) or 2 (primal-dual).
+    scheme: 0 / "backward_euler" (the reference's NODES=2) or 1 / "trapezoid" (control held over the step)."""
     L = _lib.load()
     P = pack(params)
     B = P.shape[0]
@@ -93,7 +98,7 @@ def solve_batch(params, nt: int = 200, tol: float = 1e-9, max_iter: int = 300, g
     tf = np.empty(B)
     status = np.empty(B, dtype=np.int32)
     iters = np.empty(B, dtype=np.int32)
-    o = _opts(nt, max_iter, tol, warm_start, mu_init)
+    o = _opts(nt, max_iter, tol, warm_start, mu_init, scheme)
     _lib.check(L.ascent_solve_batch(_ptr(P), B, C.byref(o), _ptr(guess), _ptr(traj), _ptr(tf), _ptr(status),
                                     _ptr(iters), _ptr(blob), device, None, 0))
     return BatchResult(P, nt, traj, tf, status, iters, blob, L.ascent_last_kernel_ms(device))

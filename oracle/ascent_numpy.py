@@ -147,7 +147,13 @@ class AscentNLP:
     Equalities: K*ns defects, then e3 (LO:173), then g1 - s1 (LO:161), g2 - s2 (LO:169).
     """
 
-    def __init__(self, P: Params, nt: int = 200, formulation: int = 0):
+    def __init__(self, P: Params, nt: int = 200, formulation: int = 0, scheme: int = 0):
+        """scheme 0 = backward Euler (the reference's NODES=2); scheme 1 = trapezoid with the control held over
+        the step (zero-order hold, MV_TYPE=0): z_k - z_{k-1} - dt/2 [f(z_k,u_k) + f(z_{k-1},u_k)] = 0 -- not a
+        reference scheme; SURVEY.md Appendix C's independent probe gives t_f = 435.227 s for it at nt=200."""
+        if scheme == 1 and formulation != 0:
+            raise NotImplementedError("trapezoid is restated for the current formulation only")
+        self.scheme = scheme
         self.P, self.nt, self.K, self.form = P, nt, nt - 1, formulation
         self.d = P.derived()
         self.h = 1.0 / (nt - 1)
@@ -200,6 +206,12 @@ class AscentNLP:
             F[:, self.iw] = d["alpha"] * Wk[:, self.iu]
         return F, gax, gay
 
+    def _prev_nodes(self, Wk):
+        """Rows (z_{k-1}, u_k), k = 1..K, with z_0 = 0: where the trapezoid rule evaluates f a second time."""
+        Wp = np.vstack([np.zeros((1, self.nw)), Wk[:-1]]).copy()
+        Wp[:, self.iu] = Wk[:, self.iu]
+        return Wp
+
     def constraints(self, v):
         Wk, tf, s1, s2 = self.split(v)
         d = self.d
@@ -208,7 +220,11 @@ class AscentNLP:
         Zprev = np.vstack([np.zeros((1, self.ns)), Z[:-1]])
         dt = self.h * self.P.T_scale * tf
         c = np.empty(self.m)
-        c[: self.ns * self.K] = (Z - Zprev - dt * F).ravel()
+        if self.scheme == 0:
+            c[: self.ns * self.K] = (Z - Zprev - dt * F).ravel()
+        else:
+            Fb, _, _ = self._rhs(self._prev_nodes(Wk))           # f(z_{k-1}, u_k)
+            c[: self.ns * self.K] = (Z - Zprev - 0.5 * dt * (F + Fb)).ravel()
         xK, yK, vxK, vyK = Wk[-1, self.ix], Wk[-1, self.iy], Wk[-1, self.ivx], Wk[-1, self.ivy]
         eta = yK + d["rho0"]
         c[-3] = eta * vyK + xK * vxK                                  # LO:173 divided by S^2
@@ -232,17 +248,29 @@ class AscentNLP:
         k = np.arange(K)
         rb, cb = k * ns, k * nw
         one = np.ones(K)
+        trap = self.scheme == 1
+        wc = 0.5 if trap else 1.0                # weight of f(z_k, u_k) in the step
         for i in range(ns):                      # d c_k / d z_k (identity) and d c_k / d z_{k-1}
             add(rb + i, cb + i, one)
             add(rb[1:] + i, cb[:-1] + i, -one[1:])
-        add(rb + self.ix, cb + self.ivx, -dt * one)
-        add(rb + self.iy, cb + self.ivy, -dt * one)
+        add(rb + self.ix, cb + self.ivx, -wc * dt * one)
+        add(rb + self.iy, cb + self.ivy, -wc * dt * one)
         for j, col in enumerate((self.ix, self.iy, self.ia, self.im)):
-            add(rb + self.ivx, cb + col, -dt * gax[:, j])
-            add(rb + self.ivy, cb + col, -dt * gay[:, j])
+            add(rb + self.ivx, cb + col, -wc * dt * gax[:, j])
+            add(rb + self.ivy, cb + col, -wc * dt * gay[:, j])
         if self.form == 0:
-            add(rb + self.ia, cb + self.iw, -dt * one)
-            add(rb + self.iw, cb + self.iu, -dt * d["alpha"] * one)
+            add(rb + self.ia, cb + self.iw, -wc * dt * one)
+            add(rb + self.iw, cb + self.iu, -dt * d["alpha"] * one)      # u_k enters both halves of the step
+        if trap:                                 # d c_k / d z_{k-1} through f(z_{k-1}, u_k), k >= 2
+            r1_, c0_ = rb[1:], cb[:-1]
+            add(r1_ + self.ix, c0_ + self.ivx, -0.5 * dt * one[1:])
+            add(r1_ + self.iy, c0_ + self.ivy, -0.5 * dt * one[1:])
+            for j, col in enumerate((self.ix, self.iy, self.ia, self.im)):
+                add(r1_ + self.ivx, c0_ + col, -0.5 * dt * gax[:-1, j])
+                add(r1_ + self.ivy, c0_ + col, -0.5 * dt * gay[:-1, j])
+            add(r1_ + self.ia, c0_ + self.iw, -0.5 * dt * one[1:])
+            Fb, _, _ = self._rhs(self._prev_nodes(Wk))
+            F = 0.5 * (F + Fb)
         for i in range(ns):                      # tf column
             add(rb + i, np.full(K, self.itf), -hT * F[:, i])
         last = (K - 1) * nw
@@ -268,6 +296,9 @@ class AscentNLP:
         hT = self.h * P.T_scale
         dt = hT * tf
         L = lam[: ns * K].reshape(K, ns)
+        Lu = L                                   # multipliers seen by u_k (its own step only)
+        if self.scheme == 1:                     # node k enters step k and step k+1, each with weight 1/2
+            L = 0.5 * (L + np.vstack([L[1:], np.zeros((1, ns))]))
         lvx, lvy = L[:, self.ivx], L[:, self.ivy]
         ax, ay, gax, gay, H = accel(Wk[:, self.ix], Wk[:, self.iy], Wk[:, self.ia], Wk[:, self.im], P,
                                     -dt * lvx, -dt * lvy)
@@ -294,7 +325,7 @@ class AscentNLP:
             addsym(tfc, cb + col, -hT * (lvx * gax[:, j] + lvy * gay[:, j]))
         if self.form == 0:
             addsym(tfc, cb + self.iw, -hT * L[:, self.ia])
-            addsym(tfc, cb + self.iu, -hT * d["alpha"] * L[:, self.iw])
+            addsym(tfc, cb + self.iu, -hT * d["alpha"] * Lu[:, self.iw])
         # terminal constraints
         last = (K - 1) * nw
         nu3, nu1, nu2 = lam[-3], lam[-2], lam[-1]

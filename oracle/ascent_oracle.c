@@ -102,6 +102,23 @@ static void rhs_f(const oder *d, const double *z, double u, double ax, double ay
   F[IA] = z[IW]; F[IW] = d->alpha * u; F[IM] = d->mrate;
 }
 
+/* Collocation scheme (global to one solve; set by the exported entry points):
+ *   0 = backward Euler, the reference's NODES=2 (LO:25):   z_k - z_{k-1} - dt f(z_k,u_k)
+ *   1 = trapezoid with the control held over the step:      z_k - z_{k-1} - dt/2 [f(z_k,u_k) + f(z_{k-1},u_k)]
+ * Scheme 1 is not a reference scheme; it is pinned by SURVEY.md Appendix C's independent probe (435.227 s). */
+static __thread int g_scheme = 0;
+
+/* step function Fc_k = f(z_k,u_k) (scheme 0) or the trapezoid mean with f(z_{k-1},u_k) (scheme 1) */
+static void step_f(const oder *d, const double *z, const double *zp, double u, double ax, double ay, double Fc[7]) {
+  rhs_f(d, z, u, ax, ay, Fc);
+  if (g_scheme == 1) {
+    double axp, ayp, Fb[7];
+    accel(d, zp[IX], zp[IY], zp[IA], zp[IM], 0, 0, &axp, &ayp, 0, 0, 0);
+    rhs_f(d, zp, u, axp, ayp, Fb);
+    for (int i = 0; i < 7; i++) Fc[i] = 0.5 * (Fc[i] + Fb[i]);
+  }
+}
+
 /* equality constraints: defects (7K), e3, g1-s1, g2-s2 */
 static void constraints(const oder *d, int K, double h, const iter_t *it, double *c) {
   double dt = h * d->T * it->sc[S_TH];
@@ -110,7 +127,7 @@ static void constraints(const oder *d, int K, double h, const iter_t *it, double
     const double *z = it->z + 7 * k, *zp = k ? z - 7 : zero;
     double ax, ay, F[7];
     accel(d, z[IX], z[IY], z[IA], z[IM], 0, 0, &ax, &ay, 0, 0, 0);
-    rhs_f(d, z, it->u[k], ax, ay, F);
+    step_f(d, z, zp, it->u[k], ax, ay, F);
     for (int i = 0; i < 7; i++) c[7 * k + i] = z[i] - zp[i] - dt * F[i];
   }
   const double *z = it->z + 7 * (K - 1);
@@ -139,6 +156,30 @@ static void solveAT(const stage_t *s, double dt, const double *r, double *v) {
   v[IVX] = vvx; v[IVY] = vvy; v[IA] = va;
   v[IM] = r[IM] + dt * (G[3] * vvx + G[7] * vvy);
   v[IW] = r[IW] + dt * va;
+}
+
+/* (d f/d z)' v */
+static void fzt(const double *G, const double *l, double *fl) {
+  fl[IX] = G[0] * l[IVX] + G[4] * l[IVY]; fl[IY] = G[1] * l[IVX] + G[5] * l[IVY];
+  fl[IVX] = l[IX]; fl[IVY] = l[IY];
+  fl[IA] = G[2] * l[IVX] + G[6] * l[IVY]; fl[IW] = l[IA];
+  fl[IM] = G[3] * l[IVX] + G[7] * l[IVY];
+}
+/* (d f/d z) v */
+static void fz(const double *G, const double *v, double *o) {
+  o[IX] = v[IVX]; o[IY] = v[IVY];
+  o[IVX] = G[0] * v[IX] + G[1] * v[IY] + G[2] * v[IA] + G[3] * v[IM];
+  o[IVY] = G[4] * v[IX] + G[5] * v[IY] + G[6] * v[IA] + G[7] * v[IM];
+  o[IA] = v[IW]; o[IW] = 0.0; o[IM] = 0.0;
+}
+/* trapezoid only: Abar = I + c F_z(previous node) maps dz_{k-1} into step k */
+static void abar_mul(const double *G, double c, const double *v, double *o) {
+  double t[7]; fz(G, v, t);
+  for (int i = 0; i < 7; i++) o[i] = v[i] + c * t[i];
+}
+static void abart_mul(const double *G, double c, const double *v, double *o) {
+  double t[7]; fzt(G, v, t);
+  for (int i = 0; i < 7; i++) o[i] = v[i] + c * t[i];
 }
 
 typedef struct {
@@ -174,27 +215,28 @@ static void work_free(work_t *w) {
 /* evaluate everything the Newton system needs at the iterate (mu enters the barrier gradient) */
 static void assemble(const oder *d, work_t *w, const iter_t *it, double mu, double dw) {
   int K = w->K; double hT = w->h * d->T, th = it->sc[S_TH], dt = hT * th;
+  /* node k enters step k with weight cs/dt (1 for backward Euler, 1/2 for trapezoid) and, for the
+   * trapezoid, step k+1 with the same weight: lt = lambda_k (+ lambda_{k+1}) */
+  const double cs = g_scheme == 1 ? 0.5 * dt : dt, hTc = g_scheme == 1 ? 0.5 * hT : hT;
   constraints(d, K, w->h, it, w->c);
-  double rth = 1.0;
+  double rth = 1.0, zero7[7] = {0};
   for (int k = 0; k < K; k++) {
     const double *z = it->z + 7 * k, *l = it->lam + 7 * k, *zb = it->zb + 6 * k;
     const double *ln = (k + 1 < K) ? l + 7 : 0;
     stage_t *s = w->st + k;
-    double ax, ay;
-    accel(d, z[IX], z[IY], z[IA], z[IM], -dt * l[IVX], -dt * l[IVY], &ax, &ay, s->G, s->G + 4, s->H);
-    rhs_f(d, z, it->u[k], ax, ay, s->F);
+    double ax, ay, lt[7];
+    for (int i = 0; i < 7; i++) lt[i] = l[i] + ((g_scheme == 1 && ln) ? ln[i] : 0.0);
+    accel(d, z[IX], z[IY], z[IA], z[IM], -cs * lt[IVX], -cs * lt[IVY], &ax, &ay, s->G, s->G + 4, s->H);
+    step_f(d, z, k ? z - 7 : zero7, it->u[k], ax, ay, s->F);
     const double *G = s->G;
-    double m11 = 1 - dt * dt * G[0], m12 = -dt * dt * G[1], m21 = -dt * dt * G[4], m22 = 1 - dt * dt * G[5];
+    double m11 = 1 - cs * cs * G[0], m12 = -cs * cs * G[1], m21 = -cs * cs * G[4], m22 = 1 - cs * cs * G[5];
     double idet = 1.0 / (m11 * m22 - m12 * m21);
     s->E[0] = m22 * idet; s->E[1] = -m12 * idet; s->E[2] = -m21 * idet; s->E[3] = m11 * idet;
-    /* F_z' lam */
+    /* F_z' lt */
     double fl[7];
-    fl[IX] = G[0] * l[IVX] + G[4] * l[IVY]; fl[IY] = G[1] * l[IVX] + G[5] * l[IVY];
-    fl[IVX] = l[IX]; fl[IVY] = l[IY];
-    fl[IA] = G[2] * l[IVX] + G[6] * l[IVY]; fl[IW] = l[IA];
-    fl[IM] = G[3] * l[IVX] + G[7] * l[IVY];
+    fzt(G, lt, fl);
     double *rz = w->rz + 7 * k, *g = w->gth + 7 * k;
-    for (int i = 0; i < 7; i++) { rz[i] = l[i] - dt * fl[i] - (ln ? ln[i] : 0.0); g[i] = -hT * fl[i]; }
+    for (int i = 0; i < 7; i++) { rz[i] = l[i] - cs * fl[i] - (ln ? ln[i] : 0.0); g[i] = -hTc * fl[i]; }
     double a = z[IA], m = z[IM], u = it->u[k];
     rz[IA] += -mu / a + mu / (d->aub - a);
     rz[IM] += -mu / m + mu / (1.0 - m);
@@ -243,20 +285,35 @@ static void assemble(const oder *d, work_t *w, const iter_t *it, double mu, doub
  * returns 0 ok, 1 wrong inertia (caller raises delta_w). Fills w->step (primal+lam+nu parts). */
 static int kkt_solve(const oder *d, work_t *w, const iter_t *it, double mu) {
   int K = w->K; double hT = w->h * d->T, th = it->sc[S_TH], dt = hT * th, be = dt * d->alpha;
+  const double cs = g_scheme == 1 ? 0.5 * dt : dt;   /* weight of f(z_k,u_k) in step k, times dt */
   double P[49] = {0}, p[3][7] = {{0}};
   double S10 = 0, S11 = 0, S12 = 0, S20 = 0, S22 = 0;
   for (int k = K - 1; k >= 0; k--) {
     const stage_t *s = w->st + k;
     const double *Q = w->Q + 49 * k;
     double N[49], Y[49], M[49], col[7], out[7];
+    if (g_scheme == 1 && k + 1 < K) {        /* P <- Abar' P Abar, p <- Abar' p with Abar = I + cs F_z(z_k) */
+      double T[49];
+      for (int c = 0; c < 7; c++) {          /* T = P Abar : column c of T = P (Abar e_c) */
+        double e[7] = {0}, ae[7]; e[c] = 1.0; abar_mul(s->G, cs, e, ae);
+        for (int i = 0; i < 7; i++) { double a = 0; for (int l = 0; l < 7; l++) a += P[i * 7 + l] * ae[l]; T[i * 7 + c] = a; }
+      }
+      for (int c = 0; c < 7; c++) {          /* P = Abar' T : column c */
+        for (int i = 0; i < 7; i++) col[i] = T[i * 7 + c];
+        abart_mul(s->G, cs, col, out);
+        for (int i = 0; i < 7; i++) P[i * 7 + c] = out[i];
+      }
+      for (int i = 0; i < 7; i++) for (int j = i + 1; j < 7; j++) { double a = 0.5 * (P[i * 7 + j] + P[j * 7 + i]); P[i * 7 + j] = P[j * 7 + i] = a; }
+      for (int j = 0; j < 3; j++) { abart_mul(s->G, cs, p[j], out); memcpy(p[j], out, 56); }
+    }
     for (int i = 0; i < 49; i++) N[i] = Q[i] + P[i];
     for (int c = 0; c < 7; c++) {           /* Y = A^-T N */
       for (int i = 0; i < 7; i++) col[i] = N[i * 7 + c];
-      solveAT(s, dt, col, out);
+      solveAT(s, cs, col, out);
       for (int i = 0; i < 7; i++) Y[i * 7 + c] = out[i];
     }
     for (int r = 0; r < 7; r++) {           /* M = Y A^-1 : row r of M = A^-T (row r of Y) */
-      solveAT(s, dt, Y + 7 * r, out);
+      solveAT(s, cs, Y + 7 * r, out);
       for (int i = 0; i < 7; i++) M[r * 7 + i] = out[i];
     }
     for (int i = 0; i < 7; i++) for (int j = i + 1; j < 7; j++) {
@@ -278,7 +335,7 @@ static int kkt_solve(const oder *d, work_t *w, const iter_t *it, double mu) {
         rc[j][i] = j == 0 ? -w->c[7 * k + i] : j == 1 ? hT * s->F[i] : 0.0;
       }
       ruj = j == 0 ? -w->ru[k] : j == 1 ? -w->gu[k] : 0.0;
-      solveAT(s, dt, n, nt);
+      solveAT(s, cs, n, nt);
       k0[j] = (be * nt[IW] + ruj) / D;
       for (int i = 0; i < 7; i++) q[j][i] = nt[i] - be * M[i * 7 + IW] * k0[j];
       for (int i = 0; i < 7; i++) {
@@ -305,11 +362,12 @@ static int kkt_solve(const oder *d, work_t *w, const iter_t *it, double mu) {
   for (int k = 0; k < K; k++) {             /* forward */
     const stage_t *s = w->st + k;
     const double *zp = k ? st.z + 7 * (k - 1) : zero, *kap = w->kap + 7 * k;
-    double xi[7], du = w->kap0[3 * k] + w->kap0[3 * k + 1] * dth + w->kap0[3 * k + 2] * dnu3;
-    for (int i = 0; i < 7; i++) { xi[i] = zp[i] - w->c[7 * k + i] + hT * s->F[i] * dth; du -= kap[i] * xi[i]; }
+    double xi[7], azp[7], du = w->kap0[3 * k] + w->kap0[3 * k + 1] * dth + w->kap0[3 * k + 2] * dnu3;
+    if (g_scheme == 1 && k > 0) abar_mul((s - 1)->G, cs, zp, azp); else memcpy(azp, zp, 56);
+    for (int i = 0; i < 7; i++) { xi[i] = azp[i] - w->c[7 * k + i] + hT * s->F[i] * dth; du -= kap[i] * xi[i]; }
     st.u[k] = du;
     xi[IW] += be * du;
-    solveA(s, dt, xi, st.z + 7 * k);
+    solveA(s, cs, xi, st.z + 7 * k);
   }
   for (int k = K - 1; k >= 0; k--) {        /* adjoint */
     const stage_t *s = w->st + k;
@@ -318,10 +376,14 @@ static int kkt_solve(const oder *d, work_t *w, const iter_t *it, double mu) {
     for (int i = 0; i < 7; i++) {
       double a = -w->rz[7 * k + i] - w->gth[7 * k + i] * dth - (k == K - 1 ? w->e3g[i] * dnu3 : 0.0);
       for (int l = 0; l < 7; l++) a -= Q[i * 7 + l] * dz[l];
-      if (k + 1 < K) a += st.lam[7 * (k + 1) + i];
       r[i] = a;
     }
-    solveAT(s, dt, r, st.lam + 7 * k);
+    if (k + 1 < K) {
+      double t[7];
+      if (g_scheme == 1) abart_mul(s->G, cs, st.lam + 7 * (k + 1), t); else memcpy(t, st.lam + 7 * (k + 1), 56);
+      for (int i = 0; i < 7; i++) r[i] += t[i];
+    }
+    solveAT(s, cs, r, st.lam + 7 * k);
   }
   /* slacks and their multipliers, bound multipliers */
   const double *dzK = st.z + 7 * (K - 1);
@@ -362,20 +424,20 @@ static double barrier(const oder *d, const iter_t *it, double mu) {
 /* optimality error E_mu (Waechter & Biegler eq. 5) */
 static double kkt_error(const oder *d, work_t *w, const iter_t *it, double mu) {
   int K = w->K; double hT = w->h * d->T, th = it->sc[S_TH], dt = hT * th;
-  double rd = 0, cc = 0, comp = 0, l1 = 0, zsum = 0;
+  const double cs = g_scheme == 1 ? 0.5 * dt : dt;
+  double rd = 0, cc = 0, comp = 0, l1 = 0, zsum = 0, zero7[7] = {0};
   constraints(d, K, w->h, it, w->c);
   for (int i = 0; i < 7 * K + 3; i++) cc = fmax(cc, fabs(w->c[i]));
   double rth = 1.0;
   for (int k = 0; k < K; k++) {
     const double *z = it->z + 7 * k, *l = it->lam + 7 * k, *zb = it->zb + 6 * k;
     const double *ln = (k + 1 < K) ? l + 7 : 0;
-    double ax, ay, G[8], F[7], fl[7], r[7];
+    double ax, ay, G[8], F[7], fl[7], r[7], lt[7];
     accel(d, z[IX], z[IY], z[IA], z[IM], 0, 0, &ax, &ay, G, G + 4, 0);
-    rhs_f(d, z, it->u[k], ax, ay, F);
-    fl[IX] = G[0] * l[IVX] + G[4] * l[IVY]; fl[IY] = G[1] * l[IVX] + G[5] * l[IVY];
-    fl[IVX] = l[IX]; fl[IVY] = l[IY]; fl[IA] = G[2] * l[IVX] + G[6] * l[IVY]; fl[IW] = l[IA];
-    fl[IM] = G[3] * l[IVX] + G[7] * l[IVY];
-    for (int i = 0; i < 7; i++) { r[i] = l[i] - dt * fl[i] - (ln ? ln[i] : 0.0); rth -= hT * F[i] * l[i]; l1 += fabs(l[i]); }
+    step_f(d, z, k ? z - 7 : zero7, it->u[k], ax, ay, F);
+    for (int i = 0; i < 7; i++) lt[i] = l[i] + ((g_scheme == 1 && ln) ? ln[i] : 0.0);
+    fzt(G, lt, fl);
+    for (int i = 0; i < 7; i++) { r[i] = l[i] - cs * fl[i] - (ln ? ln[i] : 0.0); rth -= hT * F[i] * l[i]; l1 += fabs(l[i]); }
     r[IA] += -zb[0] + zb[1]; r[IM] += -zb[2] + zb[3];
     if (k == K - 1) {
       double et = z[IY] + d->rho0, rho = sqrt(z[IX] * z[IX] + et * et);
@@ -538,6 +600,9 @@ void oracle_accel(const double *params, int n, const double *x, const double *y,
 }
 
 /* equality-constraint values at an iterate blob */
+void oracle_set_scheme(int scheme) { g_scheme = scheme == 1 ? 1 : 0; }
+int oracle_get_scheme(void) { return g_scheme; }
+
 void oracle_constraints(const double *params, int nt, const double *blob, double *c) {
   oder d; derive((const oparams *)params, &d);
   iter_t it; view((double *)blob, nt - 1, &it);

@@ -32,6 +32,12 @@ def lib():
     return L
 
 
+def set_scheme(scheme: int):
+    """0 = backward Euler (reference NODES=2), 1 = trapezoid with zero-order-hold control.  Thread-local in the
+    library; every call below that takes `scheme=` sets it first."""
+    lib().oracle_set_scheme(int(scheme))
+
+
 def pack_params(P) -> np.ndarray:
     """Params dataclass (oracle.ascent_numpy.Params) or dict -> 16 doubles."""
     get = (lambda k: P[k]) if isinstance(P, dict) else (lambda k: getattr(P, k))
@@ -46,20 +52,23 @@ def blob_size(nt):
     return lib().oracle_blob_size(nt)
 
 
-def newton_step(params16, nt, blob, mu, delta_w):
+def newton_step(params16, nt, blob, mu, delta_w, scheme=0):
     L = lib()
+    L.oracle_set_scheme(int(scheme))
     step = np.zeros_like(blob)
     rc = L.oracle_newton_step(_p(params16), nt, _p(blob), C.c_double(mu), C.c_double(delta_w), _p(step))
     return rc, step
 
 
-def constraints(params16, nt, blob):
+def constraints(params16, nt, blob, scheme=0):
+    lib().oracle_set_scheme(int(scheme))
     c = np.zeros(7 * (nt - 1) + 3)
     lib().oracle_constraints(_p(params16), nt, _p(blob), _p(c))
     return c
 
 
-def kkt_error(params16, nt, blob, mu=0.0):
+def kkt_error(params16, nt, blob, mu=0.0, scheme=0):
+    lib().oracle_set_scheme(int(scheme))
     return lib().oracle_kkt_error(_p(params16), nt, _p(blob), C.c_double(mu))
 
 
@@ -72,8 +81,9 @@ def accel(params16, x, y, a, m, px, py):
     return ax, ay, gax, gay, H
 
 
-def solve_batch(params, nt=200, max_iter=300, tol=1e-9, guess_blob=None, want_blob=False):
+def solve_batch(params, nt=200, max_iter=300, tol=1e-9, guess_blob=None, want_blob=False, scheme=0):
     """params: (batch,16).  Returns dict(traj (batch,10,nt), tf, status, iters[, blob])."""
+    lib().oracle_set_scheme(int(scheme))
     params = np.ascontiguousarray(np.atleast_2d(params), dtype=np.float64)
     B = params.shape[0]
     traj = np.zeros((B, 10, nt))

@@ -206,3 +206,24 @@ def test_non_converged_problems_are_flagged():
     bad = A.AscentParams(Ft=3000.0)
     rb = A.solve_batch(bad, NT, tol=1e-9, max_iter=60)
     assert rb.status[0] != 0
+
+
+def test_trapezoid_scheme_matches_oracle(coracle):
+    """scheme=1 (trapezoid, control held over the step; BASELINE.json configs name 'N=200 trapezoidal'):
+    not a reference scheme -- the reference's NODES=2 is backward Euler -- so it is checked against the oracle
+    in the same scheme and against SURVEY.md Appendix C's independent probe value 435.227 s."""
+    P = A.AscentParams()
+    r = A.solve_batch(P, NT, tol=1e-9, scheme="trapezoid")
+    ref = coracle.solve_batch(P.as_row()[None], NT, 300, 1e-9, scheme=1)
+    assert r.status[0] == 0 and ref["status"][0] == 0
+    assert abs(r.final_time()[0] - 435.22715) < 5e-3
+    assert abs(r.tf[0] - ref["tf"][0]) <= 1e-9 * ref["tf"][0]
+    assert np.abs(r.traj[:, :, 0] - ref["traj"][0]).max() < 1e-7
+    S = A.sweep_isp_drymass(6, 5)
+    rb = A.solve_batch(S, NT, tol=1e-9, scheme=1)
+    refb = coracle.solve_batch(S, NT, 300, 1e-9, scheme=1)
+    coracle.set_scheme(0)
+    assert np.all(rb.status == 0) and np.all(refb["status"] == 0)
+    assert np.abs(rb.tf - refb["tf"]).max() <= 1e-9 * refb["tf"].max()
+    # second order vs first order: the trapezoid answer is the mesh-converged one (Richardson of backward Euler)
+    assert abs(rb.final_time()[0] - A.solve_batch(S[:1], 400, tol=1e-9, scheme=1).final_time()[0]) < 0.01

@@ -190,3 +190,56 @@ def test_c_oracle_sweep_corners_feasible(coracle):
     assert np.all(r["status"] == 0)
     assert np.all(r["traj"][:, 9, -1] < 1.0)           # fuel not exhausted (mass <= 1, Launch_Optimiser.py:83)
     assert np.all((r["tf"] > 0.7) & (r["tf"] < 1.2))
+
+
+def test_trapezoid_scheme_numpy_and_c_agree_with_the_survey_probe(coracle):
+    """scheme=1 (trapezoid, zero-order-hold control) is not a reference scheme; it is pinned by SURVEY.md
+    Appendix C's independent single-shooting probe: t_f = 435.22715 s, final y -6072.59 m, x -287967.39 m."""
+    nlp = AscentNLP(Params(), 200, 0, scheme=1)
+    v, _, info = solve_ip(nlp, tol=1e-9, max_iter=300)
+    assert info["status"] == "converged"
+    o = nlp.outputs(v)
+    assert abs(o["final_time"] - 435.22715) < 2e-3
+    assert abs(o["final_y"] - (-6072.59)) < 1.0 and abs(o["final_x"] - (-287967.39)) < 2.0
+    p16 = coracle.pack_params(Params())
+    r = coracle.solve_batch(p16[None], 200, 300, 1e-9, scheme=1)
+    coracle.set_scheme(0)
+    assert r["status"][0] == 0 and abs(r["tf"][0] - v[nlp.itf]) <= 1e-10 * v[nlp.itf]
+    assert np.abs(o["x"] - r["traj"][0][0]).max() < 1e-8
+
+
+def test_trapezoid_newton_step_matches_generic_sparse_lu(coracle):
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+    from conftest import random_interior_blob
+    P = Params(); nt = 40; K = nt - 1
+    p16 = coracle.pack_params(P)
+    nlp = AscentNLP(P, nt, 0, scheme=1)
+    blob = random_interior_blob(nt, 3, p16, coracle)
+    mu, dw = 0.05, 0.1
+    v = np.zeros(nlp.n); lam = np.zeros(nlp.m); zL = np.zeros(nlp.n); zU = np.zeros(nlp.n)
+    Wk = v[:8 * K].reshape(K, 8)
+    Wk[:, :7] = blob[:7 * K].reshape(K, 7); Wk[:, 7] = blob[7 * K:8 * K]
+    lam[:7 * K] = blob[8 * K:15 * K]
+    zb = blob[15 * K:21 * K].reshape(K, 6); sc = blob[21 * K:]
+    base = np.arange(K) * 8
+    zL[base + 4], zU[base + 4], zL[base + 6], zU[base + 6], zL[base + 7], zU[base + 7] = zb.T
+    v[nlp.itf], zL[nlp.itf], zU[nlp.itf] = sc[0], sc[1], sc[2]
+    v[nlp.is1], v[nlp.is2], zL[nlp.is1], zL[nlp.is2] = sc[3], sc[4], sc[5], sc[6]
+    lam[-3], lam[-2], lam[-1] = sc[7], sc[8], sc[9]
+    assert np.allclose(nlp.constraints(v), coracle.constraints(p16, nt, blob, scheme=1), atol=1e-14)
+    hasL, hasU = np.isfinite(nlp.lb), np.isfinite(nlp.ub)
+    dL = np.where(hasL, v - nlp.lb, 1.0); dU = np.where(hasU, nlp.ub - v, 1.0)
+    J = nlp.jacobian(v); W = nlp.hessian(v, lam)
+    Sig = np.where(hasL, zL / dL, 0) + np.where(hasU, zU / dU, 0)
+    gphi = nlp.grad_objective(v) - np.where(hasL, mu / dL, 0) + np.where(hasU, mu / dU, 0)
+    sol = spla.splu(sp.bmat([[W + sp.diags(Sig + dw), J.T], [J, None]], format="csc")).solve(
+        -np.concatenate([gphi + J.T @ lam, nlp.constraints(v)]))
+    dx, dlam = sol[:nlp.n], sol[nlp.n:]
+    rc, step = coracle.newton_step(p16, nt, blob, mu, dw, scheme=1)
+    coracle.set_scheme(0)
+    assert rc == 0
+    dW = dx[:8 * K].reshape(K, 8)
+    assert np.abs(step[:7 * K] - dW[:, :7].ravel()).max() < 1e-8 * max(1.0, np.abs(dx).max())
+    assert np.abs(step[8 * K:15 * K] - dlam[:7 * K]).max() < 1e-8 * max(1.0, np.abs(dlam).max())
+    assert abs(step[21 * K] - dx[nlp.itf]) < 1e-9
