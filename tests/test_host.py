@@ -73,7 +73,7 @@ def test_argument_validation(lib):
     assert lib.ascent_solve_batch(None, 1, C.byref(o), None, None, None, None, None, None, 0, None, 0) == -1
     assert b"null" in lib.ascent_strerror(-1)
     P = A.AscentParams().as_row()
-    o2 = _lib.AscentOptsC(n_nodes=200, scheme=1, max_iter=10, warm_start=0, tol=1e-8, mu_init=0.0)
+    o2 = _lib.AscentOptsC(n_nodes=200, scheme=7, max_iter=10, warm_start=0, tol=1e-8, mu_init=0.0)
     rc = lib.ascent_solve_batch(P.ctypes.data_as(C.c_void_p), 1, C.byref(o2), None, None, None, None, None, None, 0, None, 0)
     assert rc == -1 and b"scheme" in lib.ascent_strerror(rc)
 
