@@ -396,6 +396,9 @@ __global__ __launch_bounds__(WAVE) void q_trial_eval(const ascent_params *params
   for (int j = 0; j < NLAD; j++) { ROW(pp, 9 + 2 * j) = lc1[j]; ROW(pp, 10 + 2 * j) = lsl[j]; }
 }
 
+#ifdef DF_STAMPS   // diagnostic build only (scripts/df_stamps.py)
+__device__ unsigned long long g_df_stamps[6];
+#endif
 // ==============================================================================================
 // q_decide_factor: per-lane decisions, then the backward factorisation
 // ==============================================================================================
@@ -531,7 +534,18 @@ __global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *par
   const double rs1 = -mu * is1 - s.nu1, rs2 = -mu * is2 - s.nu2;
   const double cg1 = tm.g1 - s.s1, cg2 = tm.g2 - s.s2;
   int bad = 0;
+#ifdef DF_STAMPS
+  long long st_[5] = {0, 0, 0, 0, 0};
+#define STAMP(i_) do { __builtin_amdgcn_sched_barrier(0); long long t1__ = clock64(); __builtin_amdgcn_sched_barrier(0); st_[i_] += t1__ - t0__; t0__ = t1__; } while (0)
+#else
+#define STAMP(i_) do { } while (0)
+#endif
   auto body = [&](InQM &cm, int k) __attribute__((always_inline)) {
+#ifdef DF_STAMPS
+    __builtin_amdgcn_sched_barrier(0);
+    long long t0__ = clock64();
+    __builtin_amdgcn_sched_barrier(0);
+#endif
     gdbl *sp = t_.st(k);
     InQV cv;
     loadQV(t_, k, cv);                    // in flight while the congruence runs
@@ -568,6 +582,7 @@ __global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *par
       for (int j = i; j < 7; j++) P[sid(i, j)] -= mw[i] * kap[j];
     }
     stn<7>(t_, sp, Q_KA, kap);
+    STAMP(0);        // matrix part: N assembly, congruence, pivot, P update (waits for the matrix loads)
     // right-hand sides 0: residual, 1: -B_theta, 2: -B_nu3
     double *rz = cv.rz;
     const double *cc = cv.cc;
@@ -592,6 +607,7 @@ __global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *par
     symv(P, n, Prc);
     ASC_UNROLL
     for (int i = 0; i < 7; i++) p0[i] = q0[i] - Prc[i];
+    STAMP(1);        // right-hand side 0 (waits for the vector loads)
     ASC_UNROLL
     for (int i = 0; i < 7; i++) n[i] = -cv.gt[i] + p1[i];
     solveAT(G, E, cs, n, nt);
@@ -608,6 +624,7 @@ __global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *par
     ASC_UNROLL
     for (int i = 0; i < 7; i++) p2[i] = nt[i] - mw[i] * k02;
     ROW(sp, Q_K0) = k00; ROW(sp, Q_K0 + 1) = k01; ROW(sp, Q_K0 + 2) = k02;
+    STAMP(2);        // right-hand sides 1 and 2
     double a10 = D * k01 * k00, a11 = D * k01 * k01, a12 = D * k01 * k02, a20 = D * k02 * k00;
     ASC_UNROLL
     for (int i = 0; i < 7; i++) {
@@ -617,10 +634,21 @@ __global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *par
       a20 -= cc[i] * p2[i];
     }
     S10 += a10; S11 += a11; S12 += a12; S20 += a20; S22 += D * k02 * k02;
+    STAMP(3);        // Schur sums
   };
+#ifdef DF_STAMPS
+  const long long tsw0_ = clock64();
+#endif
 #define LD_(k_, buf_) loadQM(t_, k_, buf_)
   ASC_SWEEP_BACKWARD(InQM, LD_, body)
 #undef LD_
+#ifdef DF_STAMPS
+  if (threadIdx.x == 0 && SCHEME == 0) {
+    st_[4] = clock64() - tsw0_;
+    for (int i = 0; i < 5; i++) atomicAdd(&g_df_stamps[i], (unsigned long long)st_[i]);
+    atomicAdd(&g_df_stamps[5], 1ull);
+  }
+#endif
   int ok = !bad;
   double dth = 0.0, dnu3 = 0.0;
   if (ok) {
@@ -960,6 +988,15 @@ __global__ __launch_bounds__(WAVE) void q_finish(const ascent_params *params, lo
 // ==============================================================================================
 // host driver
 // ==============================================================================================
+#ifdef DF_STAMPS
+extern "C" int ascent_debug_df_stamps(unsigned long long *out6, int reset) {
+  unsigned long long z[6] = {0};
+  if (hipMemcpyFromSymbol(out6, HIP_SYMBOL(g_df_stamps), sizeof z) != hipSuccess) return -1;
+  if (reset && hipMemcpyToSymbol(HIP_SYMBOL(g_df_stamps), z, sizeof z) != hipSuccess) return -1;
+  return 0;
+}
+#endif
+
 namespace ascent {
 
 size_t pipeline_ws_bytes(int K, long batch) {
