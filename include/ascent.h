@@ -97,8 +97,10 @@ const char *ascent_strerror(int code);
  * guess_or_null: blob [21K+10][batch] when o->warm_start != 0.
  * traj_out [10*n_nodes][batch], tf_out/status_out/iters_out [batch]; sol_blob_out_or_null
  * [21K+10][batch] receives the full primal-dual solution (usable as a warm start).
- * stream: hipStream_t or NULL.  The call is synchronous with respect to the host unless
- * ptr_is_device != 0 and a stream is given, in which case it only enqueues work. */
+ * stream: hipStream_t or NULL.  With host pointers the call returns after the results are in the
+ * caller's buffers.  With ptr_is_device != 0 and a stream, large batches (fused kernel) are only
+ * enqueued; small batches (split pipeline, <= 12 288 NLPs or scheme 1) synchronise the stream once
+ * per interior-point round, because the host steers the rounds, and return with all kernels enqueued. */
 int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts *o,
                        const double *guess_or_null, double *traj_out, double *tf_out,
                        int32_t *status_out, int32_t *iters_out, double *sol_blob_out_or_null,
