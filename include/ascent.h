@@ -55,6 +55,11 @@ typedef struct ascent_opts {
                           2 = full primal-dual `guess` (multipliers kept)                */
   double tol;          /* KKT error tolerance (the reference's OTOL/RTOL, :31-32)        */
   double mu_init;      /* initial barrier parameter (<=0: 0.1 cold, 1e-4 warm)           */
+  int32_t formulation; /* 0 = current script: u = angledoubledot is the MV (:96-100);
+                          1 = v1 script (PDF p26-28): the angle itself is the MV -- carried in
+                              the same arrays: angle = (angle_ub/2)(u+1), angledot = 0, and the
+                              `angledoubledot` field holds that normalised control u            */
+  int32_t reserved;    /* must be 0                                                       */
 } ascent_opts;
 
 enum ascent_status {           /* function return codes */

@@ -148,9 +148,14 @@ ASC_DEV void implicit_block(const double *G, double dt, double *E) {
   E[3] = m11 * idet;
 }
 
+// FORM 0: the current script (angle, angledot are states; u = angledoubledot).  FORM 1: the v1 script (PDF
+// p26-28, the angle itself is the MV) embedded in the same 7-slot state: the angle row is algebraic,
+// angle_k - (angle_ub/2)(u_k+1) = 0, so d f/d z loses its (angle, angledot) entry and angledot stays 0.
+
 // v = A^-1 r,  A = I - dt * df/dz  (the step Jacobian of the backward-Euler defect w.r.t. z_k)
+template <int FORM = 0>
 ASC_DEV void solveA(const double *G, const double *E, double dt, const double *r, double *v) {
-  const double vw = r[IW], vm = r[IM], va = r[IA] + dt * vw;
+  const double vw = r[IW], vm = r[IM], va = FORM == 1 ? r[IA] : r[IA] + dt * vw;
   const double t1 = r[IVX] + dt * (G[0] * r[IX] + G[1] * r[IY] + G[2] * va + G[3] * vm);
   const double t2 = r[IVY] + dt * (G[4] * r[IX] + G[5] * r[IY] + G[6] * va + G[7] * vm);
   const double vvx = E[0] * t1 + E[1] * t2, vvy = E[2] * t1 + E[3] * t2;
@@ -164,6 +169,7 @@ ASC_DEV void solveA(const double *G, const double *E, double dt, const double *r
 }
 
 // v = A^-T r
+template <int FORM = 0>
 ASC_DEV void solveAT(const double *G, const double *E, double dt, const double *r, double *v) {
   const double t1 = r[IVX] + dt * r[IX], t2 = r[IVY] + dt * r[IY];
   const double vvx = E[0] * t1 + E[2] * t2, vvy = E[1] * t1 + E[3] * t2;
@@ -174,7 +180,7 @@ ASC_DEV void solveAT(const double *G, const double *E, double dt, const double *
   v[IVY] = vvy;
   v[IA] = va;
   v[IM] = r[IM] + dt * (G[3] * vvx + G[7] * vvy);
-  v[IW] = r[IW] + dt * va;
+  v[IW] = FORM == 1 ? r[IW] : r[IW] + dt * va;
 }
 
 // N <- T N T',  T = I + c e_I e_J'   (packed symmetric N)
@@ -190,6 +196,7 @@ ASC_DEV void cong_add(double *N, double c) {
 // N <- A^-T N A^-1 as four in-place congruences (A^-T = T4 T3 T2 T1, see solveAT):
 //   T1: rows xdot,ydot += dt * rows x,y;  T2: 2x2 block E' on (xdot,ydot);
 //   T3: rows x,y,angle,mass += dt * G' (rows xdot,ydot);  T4: row angledot += dt * row angle.
+template <int FORM = 0>
 ASC_DEV void congruence(double *N, const double *G, const double *E, double dt) {
   cong_add<IVX, IX>(N, dt);
   cong_add<IVY, IY>(N, dt);
@@ -216,7 +223,7 @@ ASC_DEV void congruence(double *N, const double *G, const double *E, double dt) 
   cong_add<IA, IVY>(N, dt * G[6]);
   cong_add<IM, IVX>(N, dt * G[3]);
   cong_add<IM, IVY>(N, dt * G[7]);
-  cong_add<IW, IA>(N, dt);
+  if (FORM == 0) cong_add<IW, IA>(N, dt);
 }
 
 // y = N v for packed symmetric N
@@ -231,13 +238,14 @@ ASC_DEV void symv(const double *N, const double *v, double *y) {
 }
 
 // F_z' lambda : (d f/d z)' applied to the defect multipliers of a node
+template <int FORM = 0>
 ASC_DEV void fzt_lambda(const double *G, const double *l, double *fl) {
   fl[IX] = G[0] * l[IVX] + G[4] * l[IVY];
   fl[IY] = G[1] * l[IVX] + G[5] * l[IVY];
   fl[IVX] = l[IX];
   fl[IVY] = l[IY];
   fl[IA] = G[2] * l[IVX] + G[6] * l[IVY];
-  fl[IW] = l[IA];
+  fl[IW] = FORM == 1 ? 0.0 : l[IA];
   fl[IM] = G[3] * l[IVX] + G[7] * l[IVY];
 }
 
@@ -281,13 +289,14 @@ ASC_DEV void congruence_abar(double *N, const double *G, double c) {
 }
 
 // right-hand side f(z,u) of the scaled ODEs without the tf*T factor (Launch_Optimiser.py:114-123)
+template <int FORM = 0>
 ASC_DEV void rhs_f(const Der &d, const double *z, double u, double ax, double ay, double *F) {
   F[IX] = z[IVX];
   F[IY] = z[IVY];
   F[IVX] = ax;
   F[IVY] = ay;
-  F[IA] = z[IW];
-  F[IW] = d.alpha * u;
+  F[IA] = FORM == 1 ? 0.0 : z[IW];
+  F[IW] = FORM == 1 ? 0.0 : d.alpha * u;
   F[IM] = d.mrate;
 }
 

@@ -58,8 +58,8 @@ enum { ST_TRIAL = 0, ST_FACTOR = 1, ST_FACTORED = 2, ST_DONE = 3 };
 
 using QTile = TileT<Q_STAGE>;
 
-struct Geo {      // geometry of the workspace
-  int K, nch;
+struct Geo {      // geometry of the workspace (+ formulation: 0 current script, 1 v1 script)
+  int K, nch, form;
   __host__ __device__ size_t tile_doubles() const {
     return ((size_t)K * Q_STAGE + NSCAL + (size_t)nch * NPART) * WAVE;
   }
@@ -136,6 +136,10 @@ __global__ __launch_bounds__(WAVE) void q_init(const ascent_params *params, long
                            d.mrate * dt * (k + 1)};
       stn<7>(t_, sp, Q_IT + O_Z, z);
       ROW(sp, Q_IT + O_U) = 0.0;
+      if (g.form == 1) {       // v1: the angle is the control: angle = (ub/2)(u+1), no angular rate
+        ROW(sp, Q_IT + O_Z + IW) = 0.0;
+        ROW(sp, Q_IT + O_U) = z[IA] / (0.5 * d.aub) - 1.0;
+      }
     }
     s.th = tf0;
   }
@@ -197,7 +201,7 @@ ASC_DEV unsigned buf_off(const QTile &t_, int buf) { return t_.lane + (unsigned)
 // step, z_k - z_{k-1} - dt/2 [f(z_k,u_k) + f(z_{k-1},u_k)]: node k then enters steps k and k+1 with weight
 // 1/2 each, so every occurrence of lambda_k in the node's dual residual / Hessian weights becomes
 // lambda_k + lambda_{k+1} with step constant cs = dt/2, and the stored step function is the mean of the two f's.
-template <int SCHEME>
+template <int SCHEME, int FORM>
 __global__ __launch_bounds__(WAVE) void q_trial_eval(const ascent_params *params, long batch, Geo g,
                                                      double *ws) {
   const long p = (long)blockIdx.x * WAVE + threadIdx.x;
@@ -214,6 +218,7 @@ __global__ __launch_bounds__(WAVE) void q_trial_eval(const ascent_params *params
   const Scal st = trial_scal(d, s, ds, alpha, adu, mu, first);
   const double hT = (1.0 / K) * d.T, dt = hT * st.th, be = dt * d.alpha;
   const double cs = SCHEME == 1 ? 0.5 * dt : dt, hTc = SCHEME == 1 ? 0.5 * hT : hT;
+  const double ha = 0.5 * d.aub;            // FORM 1: angle = ha * (u + 1)
   const int cur = (int)SC(X_CUR);
   const unsigned oc = buf_off(t_, cur), on = buf_off(t_, 1 - cur);   // current / trial iterate rows
   const double mlo = mu * 1e-10, mhi = mu * 1e10;
@@ -286,19 +291,20 @@ __global__ __launch_bounds__(WAVE) void q_trial_eval(const ascent_params *params
         for (int i = 0; i < 7; i++) zj[i] = zc[i] + al[j] * zd[i];
         const double uj = uc + al[j] * ud;
         accel<0>(d, zj[IX], zj[IY], zj[IA], zj[IM], 0.0, 0.0, axj, ayj, nullptr, nullptr);
-        rhs_f(d, zj, uj, axj, ayj, Fj);
+        rhs_f<FORM>(d, zj, uj, axj, ayj, Fj);
         double zpj[7];
         ASC_UNROLL
         for (int i = 0; i < 7; i++) zpj[i] = zpc[i] + al[j] * tmp7[i];
         if (SCHEME == 1) {
           double Fb[7];
           accel<0>(d, zpj[IX], zpj[IY], zpj[IA], zpj[IM], 0.0, 0.0, axj, ayj, nullptr, nullptr);
-          rhs_f(d, zpj, uj, axj, ayj, Fb);
+          rhs_f<FORM>(d, zpj, uj, axj, ayj, Fb);
           ASC_UNROLL
           for (int i = 0; i < 7; i++) Fj[i] = 0.5 * (Fj[i] + Fb[i]);
         }
         ASC_UNROLL
-        for (int i = 0; i < 7; i++) lc1[j] += fabs(zj[i] - zpj[i] - dtl[j] * Fj[i]);
+        for (int i = 0; i < 7; i++)
+          lc1[j] += (FORM == 1 && i == IA) ? fabs(zj[IA] - ha * (uj + 1.0)) : fabs(zj[i] - zpj[i] - dtl[j] * Fj[i]);
         const double pa = zj[IA] * (d.aub - zj[IA]), pm = zj[IM] * (1.0 - zj[IM]), pu = (uj + 1.0) * (1.0 - uj);
         lsl[j] += (pa > 0.0 && pm > 0.0 && pu > 0.0) ? log(pa * pm * pu) : NAN;
         if (k == K - 1) {
@@ -320,22 +326,22 @@ __global__ __launch_bounds__(WAVE) void q_trial_eval(const ascent_params *params
     ASC_UNROLL
     for (int i = 0; i < 7; i++) lt[i] = SCHEME == 1 ? l[i] + ln[i] : l[i];
     accel<2>(d, z[IX], z[IY], z[IA], z[IM], -cs * lt[IVX], -cs * lt[IVY], ax, ay, G, H);
-    rhs_f(d, z, u, ax, ay, F);
+    rhs_f<FORM>(d, z, u, ax, ay, F);
     if (SCHEME == 1) {       // second evaluation point of the step: f(z_{k-1}, u_k)
       double Fb[7], axp, ayp;
       accel<0>(d, zp[IX], zp[IY], zp[IA], zp[IM], 0.0, 0.0, axp, ayp, nullptr, nullptr);
-      rhs_f(d, zp, u, axp, ayp, Fb);
+      rhs_f<FORM>(d, zp, u, axp, ayp, Fb);
       ASC_UNROLL
       for (int i = 0; i < 7; i++) F[i] = 0.5 * (F[i] + Fb[i]);
     }
     implicit_block(G, cs, E);
-    fzt_lambda(G, lt, fl);
+    fzt_lambda<FORM>(G, lt, fl);
     double rz[7], gt[7], cc[7];
     ASC_UNROLL
     for (int i = 0; i < 7; i++) {
-      rz[i] = l[i] - cs * fl[i] - ln[i];
+      rz[i] = (FORM == 1 && i == IA) ? l[i] - cs * fl[i] : l[i] - cs * fl[i] - ln[i];
       gt[i] = -hTc * fl[i];
-      cc[i] = z[i] - zp[i] - dt * F[i];
+      cc[i] = (FORM == 1 && i == IA) ? z[IA] - ha * (u + 1.0) : z[i] - zp[i] - dt * F[i];
       c1 += fabs(cc[i]);
       cinf = fmax(cinf, fabs(cc[i]));
       rth -= hT * F[i] * l[i];
@@ -351,8 +357,8 @@ __global__ __launch_bounds__(WAVE) void q_trial_eval(const ascent_params *params
     stn<7>(t_, sp, Q_C, cc);
     stn<7>(t_, sp, Q_RZ, rz);
     stn<7>(t_, sp, Q_GT, gt);
-    const double scr[5] = {zb[4] * id[4] + zb[5] * id[5], -be * l[IW], id[1] - id[0], id[3] - id[2],
-                           id[5] - id[4]};
+    const double ru0 = FORM == 1 ? -ha * l[IA] : -be * l[IW];      // d(lambda'c)/du
+    const double scr[5] = {zb[4] * id[4] + zb[5] * id[5], ru0, id[1] - id[0], id[3] - id[2], id[5] - id[4]};
     stn<5>(t_, sp, Q_SC, scr);
     // KKT error pieces (dual residual with the actual bound multipliers) and merit pieces
     double r[7];
@@ -374,7 +380,7 @@ __global__ __launch_bounds__(WAVE) void q_trial_eval(const ascent_params *params
     }
     ASC_UNROLL
     for (int i = 0; i < 7; i++) rd = fmax(rd, fabs(r[i]));
-    rd = fmax(rd, fabs(-be * l[IW] - zb[4] + zb[5]));
+    rd = fmax(rd, fabs(ru0 - zb[4] + zb[5]));
     ASC_UNROLL
     for (int b = 0; b < 6; b++) {
       const double pr = dist[b] * zb[b];
@@ -424,7 +430,7 @@ ASC_DEV void loadQV(const QTile &t_, int k, InQV &in) {
   in.ru0 = ROW(sp, Q_SC + 1); in.bza = ROW(sp, Q_SC + 2); in.bzm = ROW(sp, Q_SC + 3); in.bu = ROW(sp, Q_SC + 4);
 }
 
-template <int SCHEME>
+template <int SCHEME, int FORM>
 __global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *params, long batch, Geo g,
                                                         double *ws, int max_iter, double tol, int *counters) {
   const long p = (long)blockIdx.x * WAVE + threadIdx.x;
@@ -520,6 +526,8 @@ __global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *par
   const double dw = SC(X_DW);
   const double hT = (1.0 / K) * d.T, dt = hT * s.th, be = dt * d.alpha, ith = rcp(s.th);
   const double cs = SCHEME == 1 ? 0.5 * dt : dt;
+  constexpr int IB = FORM == 1 ? IA : IW;          // the defect row the control enters ...
+  const double bu = FORM == 1 ? 0.5 * d.aub : be;  // ... and its coefficient
   double P[28], p0[7], p1[7], p2[7];
   ASC_UNROLL
   for (int i = 0; i < 28; i++) P[i] = 0.0;
@@ -550,6 +558,11 @@ __global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *par
     InQV cv;
     loadQV(t_, k, cv);                    // in flight while the congruence runs
     const double *G = cm.G, *E = cm.E, *H = cm.H;
+    if (FORM == 1 && k < K - 1) {     // step k+1 does not see angle_k: drop its row and column
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) P[sid(IA, i)] = 0.0;
+      p0[IA] = 0.0; p1[IA] = 0.0; p2[IA] = 0.0;
+    }
     if (SCHEME == 1 && k < K - 1) {   // pull the value function of step k+1 back through Abar = I + cs*F_z(z_k)
       congruence_abar(P, G, cs);
       double t_[7];
@@ -569,13 +582,13 @@ __global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *par
     ASC_UNROLL
     for (int i = 0; i < 7; i++) P[sid(i, i)] += dw;
     if (k == K - 1) terminal_hessian(P, tm, s.nu3, s.nu1, s.nu2, sig1, sig2);
-    congruence(P, G, E, cs);
-    const double D = cm.R0 + dw + be * be * P[sid(IW, IW)];
+    congruence<FORM>(P, G, E, cs);
+    const double D = cm.R0 + dw + bu * bu * P[sid(IB, IB)];
     if (!(D > 0.0)) bad = 1;
     const double iD = rcp(D);
     double mw[7], kap[7];
     ASC_UNROLL
-    for (int i = 0; i < 7; i++) { mw[i] = be * P[sid(i, IW)]; kap[i] = mw[i] * iD; }
+    for (int i = 0; i < 7; i++) { mw[i] = bu * P[sid(i, IB)]; kap[i] = mw[i] * iD; }
     ASC_UNROLL
     for (int i = 0; i < 7; i++) {
       ASC_UNROLL
@@ -589,7 +602,7 @@ __global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *par
     rz[IA] += mu * cv.bza;
     rz[IM] += mu * cv.bzm;
     const double ru = cv.ru0 + mu * cv.bu;
-    const double gu = cv.ru0 * ith;
+    const double gu = FORM == 1 ? 0.0 : cv.ru0 * ith;
     if (k == K - 1) {
       const double w1 = s.nu1 + sig1 * cg1 + rs1, w2 = s.nu2 + sig2 * cg2 + rs2;
       rz[IX] += s.nu3 * tm.e3g[0] + w1 * tm.g1g[0];
@@ -600,8 +613,8 @@ __global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *par
     double n[7], nt[7], q0[7], q1[7], rc1[7], Prc[7], k00, k01, k02;
     ASC_UNROLL
     for (int i = 0; i < 7; i++) n[i] = -rz[i] + p0[i];
-    solveAT(G, E, cs, n, nt);
-    k00 = (be * nt[IW] - ru) * iD;
+    solveAT<FORM>(G, E, cs, n, nt);
+    k00 = (bu * nt[IB] - ru) * iD;
     ASC_UNROLL
     for (int i = 0; i < 7; i++) { q0[i] = nt[i] - mw[i] * k00; n[i] = -cc[i]; }
     symv(P, n, Prc);
@@ -610,8 +623,8 @@ __global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *par
     STAMP(1);        // right-hand side 0 (waits for the vector loads)
     ASC_UNROLL
     for (int i = 0; i < 7; i++) n[i] = -cv.gt[i] + p1[i];
-    solveAT(G, E, cs, n, nt);
-    k01 = (be * nt[IW] - gu) * iD;
+    solveAT<FORM>(G, E, cs, n, nt);
+    k01 = (bu * nt[IB] - gu) * iD;
     ASC_UNROLL
     for (int i = 0; i < 7; i++) { q1[i] = nt[i] - mw[i] * k01; rc1[i] = hT * cv.F[i]; }
     symv(P, rc1, Prc);
@@ -619,8 +632,8 @@ __global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *par
     for (int i = 0; i < 7; i++) p1[i] = q1[i] - Prc[i];
     cpy<7>(n, p2);
     if (k == K - 1) { n[IX] -= tm.e3g[0]; n[IY] -= tm.e3g[1]; n[IVX] -= tm.e3g[2]; n[IVY] -= tm.e3g[3]; }
-    solveAT(G, E, cs, n, nt);
-    k02 = be * nt[IW] * iD;
+    solveAT<FORM>(G, E, cs, n, nt);
+    k02 = bu * nt[IB] * iD;
     ASC_UNROLL
     for (int i = 0; i < 7; i++) p2[i] = nt[i] - mw[i] * k02;
     ROW(sp, Q_K0) = k00; ROW(sp, Q_K0 + 1) = k01; ROW(sp, Q_K0 + 2) = k02;
@@ -700,7 +713,7 @@ ASC_DEV void loadQF(const QTile &t_, int k, InQF &in) {
   ldn<3>(t_, sp, Q_K0, in.k0);
 }
 
-template <int SCHEME>
+template <int SCHEME, int FORM>
 __global__ __launch_bounds__(WAVE) void q_forward(const ascent_params *params, long batch, Geo g, double *ws) {
   const long p = (long)blockIdx.x * WAVE + threadIdx.x;
   if (p >= batch) return;
@@ -727,13 +740,14 @@ __global__ __launch_bounds__(WAVE) void q_forward(const ascent_params *params, l
       ASC_UNROLL
       for (int i = 0; i < 7; i++) dzp[i] += cs * t2_[i];
     }
+    if (FORM == 1) dzp[IA] = 0.0;     // the angle row has no coupling to the previous angle
     ASC_UNROLL
     for (int i = 0; i < 7; i++) {
       xi[i] = dzp[i] - cur_.cc[i] + hT * cur_.F[i] * dth;
       du -= cur_.ka[i] * xi[i];
     }
-    xi[IW] += be * du;
-    solveA(cur_.G, cur_.E, cs, xi, dz);
+    if (FORM == 1) xi[IA] += 0.5 * d.aub * du; else xi[IW] += be * du;
+    solveA<FORM>(cur_.G, cur_.E, cs, xi, dz);
     stn<7>(t_, sp, Q_ST + O_Z, dz);
     ROW(sp, Q_ST + O_U) = du;
     cpy<7>(dzp, dz);
@@ -843,7 +857,7 @@ ASC_DEV void loadQA(const QTile &t_, int k, InQA &in) {
   ldn<7>(t_, sp, Q_C, in.cc);
 }
 
-template <int SCHEME>
+template <int SCHEME, int FORM>
 __global__ __launch_bounds__(WAVE) void q_adjoint(const ascent_params *params, long batch, Geo g, double *ws) {
   const long p = (long)blockIdx.x * WAVE + threadIdx.x;
   if (p >= batch) return;
@@ -867,14 +881,14 @@ __global__ __launch_bounds__(WAVE) void q_adjoint(const ascent_params *params, l
     gdbl *sp = t_.st(k);
     double r[7], dl[7];
     ASC_UNROLL
-    for (int i = 0; i < 7; i++) r[i] = cur_.r[i] + dln[i];
+    for (int i = 0; i < 7; i++) r[i] = (FORM == 1 && i == IA) ? cur_.r[i] : cur_.r[i] + dln[i];
     if (SCHEME == 1) {           // Abar_{k+1}' dlambda_{k+1} = dlambda_{k+1} + cs * F_z(z_k)' dlambda_{k+1}
       double t2_[7];
       fzt_lambda(cur_.G, dln, t2_);
       ASC_UNROLL
       for (int i = 0; i < 7; i++) r[i] += cs * t2_[i];
     }
-    solveAT(cur_.G, cur_.E, cs, r, dl);
+    solveAT<FORM>(cur_.G, cur_.E, cs, r, dl);
     stn<7>(t_, sp, Q_ST + O_L, dl);
     ASC_UNROLL
     for (int i = 0; i < 7; i++) cl += cur_.cc[i] * dl[i];
@@ -1000,17 +1014,17 @@ extern "C" int ascent_debug_df_stamps(unsigned long long *out6, int reset) {
 namespace ascent {
 
 size_t pipeline_ws_bytes(int K, long batch) {
-  Geo g{K, (K + CHUNK - 1) / CHUNK};
+  Geo g{K, (K + CHUNK - 1) / CHUNK, 0};
   const size_t tiles = (size_t)((batch + WAVE - 1) / WAVE);
   return tiles * g.tile_doubles() * sizeof(double) + 64;   // + counters
 }
 
 #define PCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf(err, errlen, "%s: %s", #call, hipGetErrorString(e_)); return ASCENT_E_HIP; } } while (0)
 
-int pipeline_run(const ascent_params *dp, long batch, int K, int scheme, double *ws, const double *dguess, int warm,
+int pipeline_run(const ascent_params *dp, long batch, int K, int scheme, int form, double *ws, const double *dguess, int warm,
                  int max_iter, double tol, double mu0, double *dtraj, double *dtf, int *dstatus, int *diters,
                  double *dblob, hipStream_t stream, PipelineStats *stats, char *err, size_t errlen) {
-  Geo g{K, (K + CHUNK - 1) / CHUNK};
+  Geo g{K, (K + CHUNK - 1) / CHUNK, form};
   const unsigned tiles = (unsigned)((batch + WAVE - 1) / WAVE);
   int *counters = (int *)((char *)ws + (size_t)tiles * g.tile_doubles() * sizeof(double));
   int host_cnt[3];
@@ -1024,11 +1038,15 @@ int pipeline_run(const ascent_params *dp, long batch, int K, int scheme, double 
   // points plus <= 40 rejected trials and ~50 refactorisations per iteration, so the loop terminates.
   for (long round = 0;; round++) {
     if (round > 100L * (max_iter + 2)) { snprintf(err, errlen, "pipeline did not terminate"); return ASCENT_E_HIP; }
-    if (scheme == 1) hipLaunchKernelGGL(q_trial_eval<1>, dim3(tiles, g.nch), dim3(WAVE), 0, stream, dp, batch, g, ws);
-    else hipLaunchKernelGGL(q_trial_eval<0>, dim3(tiles, g.nch), dim3(WAVE), 0, stream, dp, batch, g, ws);
+#define ASC_LAUNCH(KERNEL, GRID, ...)                                                                               \
+  do {                                                                                                              \
+    if (form == 1) hipLaunchKernelGGL((KERNEL<0, 1>), GRID, dim3(WAVE), 0, stream, __VA_ARGS__);                    \
+    else if (scheme == 1) hipLaunchKernelGGL((KERNEL<1, 0>), GRID, dim3(WAVE), 0, stream, __VA_ARGS__);            \
+    else hipLaunchKernelGGL((KERNEL<0, 0>), GRID, dim3(WAVE), 0, stream, __VA_ARGS__);                              \
+  } while (0)
+    ASC_LAUNCH(q_trial_eval, dim3(tiles, g.nch), dp, batch, g, ws);
     PCHK(hipMemsetAsync(counters, 0, 3 * sizeof(int), stream));
-    if (scheme == 1) hipLaunchKernelGGL(q_decide_factor<1>, dim3(tiles), dim3(WAVE), 0, stream, dp, batch, g, ws, max_iter, tol, counters);
-    else hipLaunchKernelGGL(q_decide_factor<0>, dim3(tiles), dim3(WAVE), 0, stream, dp, batch, g, ws, max_iter, tol, counters);
+    ASC_LAUNCH(q_decide_factor, dim3(tiles), dp, batch, g, ws, max_iter, tol, counters);
     PCHK(hipMemcpyAsync(host_cnt, counters, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
     launches += 2;
     PCHK(hipStreamSynchronize(stream));
@@ -1036,11 +1054,9 @@ int pipeline_run(const ascent_params *dp, long batch, int K, int scheme, double 
     if (debug) fprintf(stderr, "[ascent pipeline] round %ld: pending %d (refactor %d), stepping %d\n", round, n_pending, host_cnt[2], n_factored);
     if (n_pending == 0 && n_factored == 0) break;
     if (n_factored > 0) {
-      if (scheme == 1) hipLaunchKernelGGL(q_forward<1>, dim3(tiles), dim3(WAVE), 0, stream, dp, batch, g, ws);
-      else hipLaunchKernelGGL(q_forward<0>, dim3(tiles), dim3(WAVE), 0, stream, dp, batch, g, ws);
+      ASC_LAUNCH(q_forward, dim3(tiles), dp, batch, g, ws);
       hipLaunchKernelGGL(q_local, dim3(tiles, g.nch), dim3(WAVE), 0, stream, dp, batch, g, ws);
-      if (scheme == 1) hipLaunchKernelGGL(q_adjoint<1>, dim3(tiles), dim3(WAVE), 0, stream, dp, batch, g, ws);
-      else hipLaunchKernelGGL(q_adjoint<0>, dim3(tiles), dim3(WAVE), 0, stream, dp, batch, g, ws);
+      ASC_LAUNCH(q_adjoint, dim3(tiles), dp, batch, g, ws);
       launches += 3;
     }
   }

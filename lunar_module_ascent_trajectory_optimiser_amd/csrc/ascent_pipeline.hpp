@@ -15,7 +15,7 @@ size_t pipeline_ws_bytes(int K, long batch);
 
 // Solve; all pointers are device pointers.  Synchronises `stream` once per interior-point iteration
 // (it reads three counters to steer the lanes' state machines).  Returns ASCENT_OK or ASCENT_E_HIP.
-int pipeline_run(const ascent_params *dp, long batch, int K, int scheme, double *ws, const double *dguess, int warm,
+int pipeline_run(const ascent_params *dp, long batch, int K, int scheme, int form, double *ws, const double *dguess, int warm,
                  int max_iter, double tol, double mu0, double *dtraj, double *dtf, int *dstatus, int *diters,
                  double *dblob, hipStream_t stream, PipelineStats *stats, char *err, size_t errlen);
 

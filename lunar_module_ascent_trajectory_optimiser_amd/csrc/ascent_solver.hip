@@ -887,6 +887,8 @@ int ensure_ws(int dev, size_t bytes) {
 int check_common(const ascent_params *p, int64_t batch, const ascent_opts *o, int device_id) {
   if (!p || !o || batch <= 0) { snprintf(g_err, sizeof g_err, "null params/opts or batch <= 0"); return ASCENT_E_ARG; }
   if (o->n_nodes < 3 || o->n_nodes > 100000) { snprintf(g_err, sizeof g_err, "n_nodes out of range"); return ASCENT_E_ARG; }
+  if (o->formulation != 0 && o->formulation != 1) { snprintf(g_err, sizeof g_err, "formulation %d not supported (0 = current script, 1 = v1 script)", o->formulation); return ASCENT_E_ARG; }
+  if (o->formulation == 1 && o->scheme != 0) { snprintf(g_err, sizeof g_err, "formulation 1 is available with scheme 0 only"); return ASCENT_E_ARG; }
   if (o->scheme != 0 && o->scheme != 1) { snprintf(g_err, sizeof g_err, "scheme %d not supported (0 = backward Euler, the reference's NODES=2; 1 = trapezoid)", o->scheme); return ASCENT_E_ARG; }
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { snprintf(g_err, sizeof g_err, "no HIP device available"); return ASCENT_E_NODEVICE; }
@@ -914,7 +916,7 @@ int ascent_debug_profile(unsigned long long *out8, int reset) {
 }
 #endif
 
-int ascent_version(void) { return 102; }
+int ascent_version(void) { return 103; }
 
 int ascent_device_count(void) {
   int n = 0;
@@ -958,7 +960,8 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
   const int K = o->n_nodes - 1, nt = o->n_nodes;
   const size_t rows = 21 * (size_t)K + NSC;
   const int lpt = lanes_per_tile(batch);
-  const bool split = o->scheme == 1 || use_split_pipeline(batch);   // the trapezoid scheme exists in the split pipeline only
+  // the trapezoid scheme and the v1 formulation exist in the split pipeline only
+  const bool split = o->scheme == 1 || o->formulation == 1 || use_split_pipeline(batch);
   rc = ensure_ws(device_id, split ? pipeline_ws_bytes(K, (long)batch) : ws_bytes(K, batch, lpt));
   if (rc) return rc;
   DeviceWs &w = g_ws[device_id];
@@ -989,7 +992,7 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
   const unsigned grid = (unsigned)((batch + lpt - 1) / lpt);
   HIPCHK(hipEventRecord(w.ev0, stream));
   if (split) {
-    rc = pipeline_run(dp, (long)batch, K, (int)o->scheme, w.ws, dguess, (int)o->warm_start, (int)o->max_iter, o->tol, mu0, dtraj,
+    rc = pipeline_run(dp, (long)batch, K, (int)o->scheme, (int)o->formulation, w.ws, dguess, (int)o->warm_start, (int)o->max_iter, o->tol, mu0, dtraj,
                       dtf, dstatus, diters, dblob, stream, nullptr, g_err, sizeof g_err);
     if (rc) return rc;
   } else {
@@ -1015,7 +1018,7 @@ int ascent_eval_nodes(const ascent_params *p, int64_t batch, const ascent_opts *
   int rc = check_common(p, batch, o, device_id);
   if (rc) return rc;
   if (!iterate || !defects || !jac_blocks || !hess_blocks) { snprintf(g_err, sizeof g_err, "null pointer"); return ASCENT_E_ARG; }
-  if (o->scheme != 0) { snprintf(g_err, sizeof g_err, "ascent_eval_nodes: scheme 0 only"); return ASCENT_E_ARG; }
+  if (o->scheme != 0 || o->formulation != 0) { snprintf(g_err, sizeof g_err, "ascent_eval_nodes: scheme 0, formulation 0 only"); return ASCENT_E_ARG; }
   std::lock_guard<std::mutex> lock(g_mu[device_id]);
   HIPCHK(hipSetDevice(device_id));
   const int K = o->n_nodes - 1;
@@ -1040,7 +1043,7 @@ int ascent_kkt_step(const ascent_params *p, int64_t batch, const ascent_opts *o,
   int rc = check_common(p, batch, o, device_id);
   if (rc) return rc;
   if (!iterate || !mu || !delta_w || !step || !inertia_out) { snprintf(g_err, sizeof g_err, "null pointer"); return ASCENT_E_ARG; }
-  if (o->scheme != 0) { snprintf(g_err, sizeof g_err, "ascent_kkt_step: scheme 0 only"); return ASCENT_E_ARG; }
+  if (o->scheme != 0 || o->formulation != 0) { snprintf(g_err, sizeof g_err, "ascent_kkt_step: scheme 0, formulation 0 only"); return ASCENT_E_ARG; }
   std::lock_guard<std::mutex> lock(g_mu[device_id]);
   HIPCHK(hipSetDevice(device_id));
   const int K = o->n_nodes - 1;

@@ -7,6 +7,9 @@ offers the calls that script makes (`GEKKO()`, `m.time`, `
 `.value`, `.STATUS/.DCOST/...`) and, at `solve()`, maps the declared model onto the built-in ascent NLP
 of libascent (include/ascent.h) instead of shipping it to a general NLP solver.
 
+Both model variants of the reference are mapped: the current script (angledoubledot is the MV) and the v1
+script of the PDF appendix (the angle itself is the MV; no angledot / angledoubledot variables).
+
 It is not a general modelling language.  `solve()` *recognises* the ascent model family:
   1. variables are found by the names the reference gives them (`name='y'`, `'ydot'`, ... :83-96);
   2. the physical constants are read from the named `m.Const`s (:55-63, 74, 107-108) and the plain
@@ -244,9 +247,13 @@ class GEKKO:
         nt = len(self.time)
         if nt < 3 or not np.allclose(self.time, np.linspace(0.0, 1.0, nt)):
             raise ModelNotRecognised("m.time must be np.linspace(0, 1, nt)")
-        R = {n: self._role(n) for n in ROLE_NAMES}
-        if R["angledoubledot"].kind != "mv":
-            raise ModelNotRecognised("the v1 formulation (angle itself is the MV) is not available on the GPU path yet")
+        names = {v.name for v in self._leaves}
+        v1 = "angledoubledot" not in names and "angledot" not in names       # v1 script: the angle itself is the MV
+        roles = tuple(n for n in ROLE_NAMES if not (v1 and n in ("angledot", "angledoubledot")))
+        R = {n: self._role(n) for n in roles}
+        ctrl = R["angle"] if v1 else R["angledoubledot"]
+        if ctrl.kind != "mv" or not ctrl.STATUS:
+            raise ModelNotRecognised("the manipulated variable (angledoubledot, or angle in the v1 script) must be an MV with STATUS=1")
         fvs = [v for v in self._leaves if v.kind == "fv"]
         if len(fvs) != 1 or self._objective is None or self._objective[0] != "min" or self._objective[1] is not fvs[0]:
             raise ModelNotRecognised("the objective must be m.Minimize(tf) with tf the single FV")
@@ -276,9 +283,9 @@ class GEKKO:
                 eqc.append(r)
             else:
                 raise ModelNotRecognised("unsupported relation in the model")
-        states = ("x", "y", "xdot", "ydot", "angle", "angledot", "mass")
+        states = ("x", "y", "xdot", "ydot", "mass") if v1 else ("x", "y", "xdot", "ydot", "angle", "angledot", "mass")
         if {id(v) for v in ode} != {id(R[n]) for n in states} or {id(v) for v in alg} != {id(R["xdoubledot"]), id(R["ydoubledot"])}:
-            raise ModelNotRecognised("expected 7 differential equations and the two acceleration definitions")
+            raise ModelNotRecognised("expected %d differential equations and the two acceleration definitions" % len(states))
         if len(ineq) != 2 or len(eqc) != 1 or len(params) != 2:
             raise ModelNotRecognised("expected the three masked terminal constraints (two >=, one ==) and two mask Params")
 
@@ -291,7 +298,7 @@ class GEKKO:
 
         # plain-number constants recovered by probing the linear ODE right-hand sides (tf = 1)
         T = float(ode[R["y"]].eval(env0(ydot=1.0)))                              # final_time, :38,114
-        alpha = float(ode[R["angledot"]].eval(env0(angledoubledot=1.0))) / T       # :109,121
+        alpha = 5e-4 / 3 if v1 else float(ode[R["angledot"]].eval(env0(angledoubledot=1.0))) / T   # :109,121
         mrate = float(ode[R["mass"]].eval(env0())) / T                            # mflow, :65,123
         # terminal masks: which Param is which is decided by their last entries (:158-168)
         pv = {p: np.asarray(p.value, dtype=float) for p in params}
@@ -316,18 +323,19 @@ class GEKKO:
         r_apo = 2.0 * r_avg - r_peri
         P = AscentParams(G=G, M=M, R0=R0, Ft=Ft, M0=M0, mdot=mrate * ms, fuel_mass=ms, mass_scalar=ms,
                          ang_acc_max=3.0 * alpha, r_peri=r_peri, r_apo=r_apo, T_scale=T,
-                         angle_ub=R["angle"].ub, tf_lb=tf.lb, tf_ub=tf.ub, dcost=float(R["angledoubledot"].DCOST or 0.0))
+                         angle_ub=R["angle"].ub, tf_lb=tf.lb, tf_ub=tf.ub, dcost=float(ctrl.DCOST or 0.0))
         # bounds, initial conditions
-        if (R["mass"].lb, R["mass"].ub) != (0, 1) or (R["angledoubledot"].lb, R["angledoubledot"].ub) != (-1, 1) \
+        if (R["mass"].lb, R["mass"].ub) != (0, 1) or (not v1 and (ctrl.lb, ctrl.ub) != (-1, 1)) \
                 or R["angle"].lb != 0 or R["angle"].ub is None or tf.lb is None or tf.ub is None:
             raise ModelNotRecognised("bounds differ from the model family (mass in [0,1], u in [-1,1], angle in [0,ub], tf in [lb,ub])")
+        self._formulation = 1 if v1 else 0
         for n in ("y", "x", "ydot", "xdot", "angle", "mass"):
             if R[n].fixed.get(0) != 0:
                 raise ModelNotRecognised(f"initial condition m.fix({n}, pos=0, val=0) missing (Launch_Optimiser.py:145-151)")
-        self._verify(P, R, tf, ode, alg, rr[0], rs[0], eqc[0], rad, vel)
+        self._verify(P, R, tf, ode, alg, rr[0], rs[0], eqc[0], rad, vel, v1)
         return P, R, tf
 
-    def _verify(self, P, R, tf, ode, alg, rr, rs, eq3, rad, vel):
+    def _verify(self, P, R, tf, ode, alg, rr, rs, eq3, rad, vel, v1=False):
         """Every declared equation against the built-in model at random points (relative 1e-9)."""
         rng = np.random.default_rng(20251226)
         S, GM = P.r_peri, P.G * P.M
@@ -337,7 +345,7 @@ class GEKKO:
                      mass=rng.uniform(0, 1), xdoubledot=rng.uniform(-1, 1), ydoubledot=rng.uniform(-1, 1))
             tfv = rng.uniform(0.5, 1.0)
             env = {leaf: 0.0 for leaf in self._leaves}
-            env.update({R[k]: val for k, val in v.items()})
+            env.update({R[k]: val for k, val in v.items() if k in R})
             env[tf] = tfv
             X, Y = S * v["x"], S * v["y"] + P.R0
             Rr = math.hypot(X, Y)
@@ -347,9 +355,10 @@ class GEKKO:
             xdd = (P.Ft / (mp * Rr) * (X * c - Y * s) - X * GM / Rr ** 3) / S          # :133-136
             T = P.T_scale
             want = {R["y"]: tfv * T * v["ydot"], R["ydot"]: tfv * T * v["ydoubledot"], R["x"]: tfv * T * v["xdot"],
-                    R["xdot"]: tfv * T * v["xdoubledot"], R["angle"]: tfv * T * v["angledot"],
-                    R["angledot"]: tfv * T * v["angledoubledot"] * P.ang_acc_max / 3.0,
-                    R["mass"]: tfv * T * P.mdot / P.fuel_mass}
+                    R["xdot"]: tfv * T * v["xdoubledot"], R["mass"]: tfv * T * P.mdot / P.fuel_mass}
+            if not v1:
+                want[R["angle"]] = tfv * T * v["angledot"]
+                want[R["angledot"]] = tfv * T * v["angledoubledot"] * P.ang_acc_max / 3.0
             checks = [(float(ode[k].eval(env)), w, f"d{k.name}/dt") for k, w in want.items()]
             checks += [(float(alg[R["ydoubledot"]].eval(env)), ydd, "ydoubledot"),
                        (float(alg[R["xdoubledot"]].eval(env)), xdd, "xdoubledot")]
@@ -370,7 +379,7 @@ class GEKKO:
         if solver is None:
             from .solver import solve_batch as solver
         max_iter = int(min(max(int(self.options.MAX_ITER), 1), 3000))
-        res = solver(P, nt=nt, tol=1e-9, max_iter=max_iter)
+        res = solver(P, nt=nt, tol=1e-9, max_iter=max_iter, formulation=self._formulation)
         self.result = res
         ok = int(res.status[0]) == 0
         if disp:
@@ -380,7 +389,7 @@ class GEKKO:
             print(" ----------------------------------------------------------------")
         if not ok:
             raise Exception("@error: Solution Not Found (libascent status %d)" % int(res.status[0]))   # GEKKO raises a bare Exception too
-        for name in ROLE_NAMES:
+        for name in R:
             R[name].value = [float(v) for v in res.field(name)[:, 0]]
         tf.value = [float(res.tf[0])] * nt
         self.options.APPSTATUS, self.options.SOLVESTATUS, self.options.OBJFCNVAL = 1, 1, float(res.tf[0])

@@ -22,10 +22,14 @@ def blob_rows(nt: int) -> int:
 SCHEMES = {"backward_euler": 0, "trapezoid": 1}
 
 
-def _opts(nt, max_iter, tol, warm_start, mu_init, scheme=0):
+FORMULATIONS = {"current": 0, "v1": 1}
+
+
+def _opts(nt, max_iter, tol, warm_start, mu_init, scheme=0, formulation=0):
     scheme = SCHEMES.get(scheme, scheme)
+    formulation = FORMULATIONS.get(formulation, formulation)
     return _lib.AscentOptsC(n_nodes=nt, scheme=int(scheme), max_iter=max_iter, warm_start=warm_start, tol=tol,
-                            mu_init=mu_init)
+                            mu_init=mu_init, formulation=int(formulation), reserved=0)
 
 
 def _ptr(a):
@@ -78,10 +82,11 @@ class BatchResult:
 
 def solve_batch(params, nt: int = 200, tol: float = 1e-9, max_iter: int = 300, guess: np.ndarray | None = None,
                 warm_start: int | None = None, mu_init: float = 0.0, device: int = 0, want_traj: bool = True,
-                want_blob: bool = False, scheme=0) -> BatchResult:
+                want_blob: bool = False, scheme=0, formulation=0) -> BatchResult:
     """Solve a batch of ascent NLPs on one GPU.  params: AscentParams | list | (batch,16) array.
     guess: (21K+10, batch) blob, with warm_start 1 (primal only) or 2 (primal-dual).
-    scheme: 0 / "backward_euler" (the reference's NODES=2) or 1 / "trapezoid" (control held over the step)."""
+    scheme: 0 / "backward_euler" (the reference's NODES=2) or 1 / "trapezoid" (control held over the step).
+    formulation: 0 / "current" or 1 / "v1" (the PDF appendix script: the angle is the MV; see include/ascent.h)."""
     L = _lib.load()
     P = pack(params)
     B = P.shape[0]
@@ -98,7 +103,7 @@ def solve_batch(params, nt: int = 200, tol: float = 1e-9, max_iter: int = 300, g
     tf = np.empty(B)
     status = np.empty(B, dtype=np.int32)
     iters = np.empty(B, dtype=np.int32)
-    o = _opts(nt, max_iter, tol, warm_start, mu_init, scheme)
+    o = _opts(nt, max_iter, tol, warm_start, mu_init, scheme, formulation)
     _lib.check(L.ascent_solve_batch(_ptr(P), B, C.byref(o), _ptr(guess), _ptr(traj), _ptr(tf), _ptr(status),
                                     _ptr(iters), _ptr(blob), device, None, 0))
     return BatchResult(P, nt, traj, tf, status, iters, blob, L.ascent_last_kernel_ms(device))

@@ -96,17 +96,24 @@ static void view(double *b, int K, iter_t *it) {
 
 typedef struct { double G[8], H[10], F[7], E[4]; } stage_t;
 
-/* rhs of the scaled ODEs without tf*T (LO:114-123) */
-static void rhs_f(const oder *d, const double *z, double u, double ax, double ay, double F[7]) {
-  F[IX] = z[IVX]; F[IY] = z[IVY]; F[IVX] = ax; F[IVY] = ay;
-  F[IA] = z[IW]; F[IW] = d->alpha * u; F[IM] = d->mrate;
-}
-
 /* Collocation scheme (global to one solve; set by the exported entry points):
  *   0 = backward Euler, the reference's NODES=2 (LO:25):   z_k - z_{k-1} - dt f(z_k,u_k)
  *   1 = trapezoid with the control held over the step:      z_k - z_{k-1} - dt/2 [f(z_k,u_k) + f(z_{k-1},u_k)]
  * Scheme 1 is not a reference scheme; it is pinned by SURVEY.md Appendix C's independent probe (435.227 s). */
 static __thread int g_scheme = 0;
+/* Formulation (global to one solve):
+ *   0 = current script: angle and angledot are states, u = angledoubledot is the MV (LO:94-100,120-121)
+ *   1 = v1 script (PDF p26-28): the angle itself is the MV.  Embedded in the same 7-slot state vector: the
+ *       angle row becomes algebraic,  angle_k - (angle_ub/2)(u_k + 1) = 0  with u in [-1,1] (so angle in
+ *       [0, angle_ub], the MV's bounds), it has no coupling to angle_{k-1}, and angledot stays 0. */
+static __thread int g_form = 0;
+
+/* rhs of the scaled ODEs without tf*T (LO:114-123) */
+static void rhs_f(const oder *d, const double *z, double u, double ax, double ay, double F[7]) {
+  F[IX] = z[IVX]; F[IY] = z[IVY]; F[IVX] = ax; F[IVY] = ay;
+  F[IA] = z[IW]; F[IW] = d->alpha * u; F[IM] = d->mrate;
+  if (g_form == 1) { F[IA] = 0.0; F[IW] = 0.0; }
+}
 
 /* step function Fc_k = f(z_k,u_k) (scheme 0) or the trapezoid mean with f(z_{k-1},u_k) (scheme 1) */
 static void step_f(const oder *d, const double *z, const double *zp, double u, double ax, double ay, double Fc[7]) {
@@ -129,6 +136,7 @@ static void constraints(const oder *d, int K, double h, const iter_t *it, double
     accel(d, z[IX], z[IY], z[IA], z[IM], 0, 0, &ax, &ay, 0, 0, 0);
     step_f(d, z, zp, it->u[k], ax, ay, F);
     for (int i = 0; i < 7; i++) c[7 * k + i] = z[i] - zp[i] - dt * F[i];
+    if (g_form == 1) c[7 * k + IA] = z[IA] - 0.5 * d->aub * (it->u[k] + 1.0);
   }
   const double *z = it->z + 7 * (K - 1);
   double et = z[IY] + d->rho0;
@@ -139,7 +147,7 @@ static void constraints(const oder *d, int K, double h, const iter_t *it, double
 
 static void solveA(const stage_t *s, double dt, const double *r, double *v) {
   const double *G = s->G, *E = s->E;
-  double vw = r[IW], vm = r[IM], va = r[IA] + dt * vw;
+  double vw = r[IW], vm = r[IM], va = r[IA] + (g_form == 1 ? 0.0 : dt * vw);
   double t1 = r[IVX] + dt * (G[0] * r[IX] + G[1] * r[IY] + G[2] * va + G[3] * vm);
   double t2 = r[IVY] + dt * (G[4] * r[IX] + G[5] * r[IY] + G[6] * va + G[7] * vm);
   double vvx = E[0] * t1 + E[1] * t2, vvy = E[2] * t1 + E[3] * t2;
@@ -155,14 +163,14 @@ static void solveAT(const stage_t *s, double dt, const double *r, double *v) {
   v[IY] = r[IY] + dt * (G[1] * vvx + G[5] * vvy);
   v[IVX] = vvx; v[IVY] = vvy; v[IA] = va;
   v[IM] = r[IM] + dt * (G[3] * vvx + G[7] * vvy);
-  v[IW] = r[IW] + dt * va;
+  v[IW] = r[IW] + (g_form == 1 ? 0.0 : dt * va);
 }
 
 /* (d f/d z)' v */
 static void fzt(const double *G, const double *l, double *fl) {
   fl[IX] = G[0] * l[IVX] + G[4] * l[IVY]; fl[IY] = G[1] * l[IVX] + G[5] * l[IVY];
   fl[IVX] = l[IX]; fl[IVY] = l[IY];
-  fl[IA] = G[2] * l[IVX] + G[6] * l[IVY]; fl[IW] = l[IA];
+  fl[IA] = G[2] * l[IVX] + G[6] * l[IVY]; fl[IW] = g_form == 1 ? 0.0 : l[IA];
   fl[IM] = G[3] * l[IVX] + G[7] * l[IVY];
 }
 /* (d f/d z) v */
@@ -236,12 +244,12 @@ static void assemble(const oder *d, work_t *w, const iter_t *it, double mu, doub
     double fl[7];
     fzt(G, lt, fl);
     double *rz = w->rz + 7 * k, *g = w->gth + 7 * k;
-    for (int i = 0; i < 7; i++) { rz[i] = l[i] - cs * fl[i] - (ln ? ln[i] : 0.0); g[i] = -hTc * fl[i]; }
+    for (int i = 0; i < 7; i++) { rz[i] = l[i] - cs * fl[i] - ((ln && !(g_form == 1 && i == IA)) ? ln[i] : 0.0); g[i] = -hTc * fl[i]; }
     double a = z[IA], m = z[IM], u = it->u[k];
     rz[IA] += -mu / a + mu / (d->aub - a);
     rz[IM] += -mu / m + mu / (1.0 - m);
-    w->ru[k] = -dt * d->alpha * l[IW] - mu / (u + 1.0) + mu / (1.0 - u);
-    w->gu[k] = -hT * d->alpha * l[IW];
+    w->ru[k] = (g_form == 1 ? -0.5 * d->aub * l[IA] : -dt * d->alpha * l[IW]) - mu / (u + 1.0) + mu / (1.0 - u);
+    w->gu[k] = g_form == 1 ? 0.0 : -hT * d->alpha * l[IW];
     w->R[k] = zb[4] / (u + 1.0) + zb[5] / (1.0 - u) + dw;
     for (int i = 0; i < 7; i++) rth -= hT * s->F[i] * l[i];
     double *Q = w->Q + 49 * k;
@@ -286,6 +294,8 @@ static void assemble(const oder *d, work_t *w, const iter_t *it, double mu, doub
 static int kkt_solve(const oder *d, work_t *w, const iter_t *it, double mu) {
   int K = w->K; double hT = w->h * d->T, th = it->sc[S_TH], dt = hT * th, be = dt * d->alpha;
   const double cs = g_scheme == 1 ? 0.5 * dt : dt;   /* weight of f(z_k,u_k) in step k, times dt */
+  const int IB = g_form == 1 ? IA : IW;              /* the defect row the control enters ... */
+  be = g_form == 1 ? 0.5 * d->aub : be;              /* ... and its coefficient */
   double P[49] = {0}, p[3][7] = {{0}};
   double S10 = 0, S11 = 0, S12 = 0, S20 = 0, S22 = 0;
   for (int k = K - 1; k >= 0; k--) {
@@ -306,6 +316,10 @@ static int kkt_solve(const oder *d, work_t *w, const iter_t *it, double mu) {
       for (int i = 0; i < 7; i++) for (int j = i + 1; j < 7; j++) { double a = 0.5 * (P[i * 7 + j] + P[j * 7 + i]); P[i * 7 + j] = P[j * 7 + i] = a; }
       for (int j = 0; j < 3; j++) { abart_mul(s->G, cs, p[j], out); memcpy(p[j], out, 56); }
     }
+    if (g_form == 1 && k + 1 < K) {          /* step k+1 does not see angle_k: drop its row/column */
+      for (int i = 0; i < 7; i++) { P[IA * 7 + i] = 0.0; P[i * 7 + IA] = 0.0; }
+      for (int j = 0; j < 3; j++) p[j][IA] = 0.0;
+    }
     for (int i = 0; i < 49; i++) N[i] = Q[i] + P[i];
     for (int c = 0; c < 7; c++) {           /* Y = A^-T N */
       for (int i = 0; i < 7; i++) col[i] = N[i * 7 + c];
@@ -319,11 +333,11 @@ static int kkt_solve(const oder *d, work_t *w, const iter_t *it, double mu) {
     for (int i = 0; i < 7; i++) for (int j = i + 1; j < 7; j++) {
       double a = 0.5 * (M[i * 7 + j] + M[j * 7 + i]); M[i * 7 + j] = M[j * 7 + i] = a;
     }
-    double D = w->R[k] + be * be * M[IW * 7 + IW];
+    double D = w->R[k] + be * be * M[IB * 7 + IB];
     if (!(D > 0.0)) return 1;
     w->Dp[k] = D;
     double *kap = w->kap + 7 * k;
-    for (int i = 0; i < 7; i++) kap[i] = be * M[i * 7 + IW] / D;
+    for (int i = 0; i < 7; i++) kap[i] = be * M[i * 7 + IB] / D;
     for (int i = 0; i < 7; i++) for (int j = 0; j < 7; j++) P[i * 7 + j] = M[i * 7 + j] - D * kap[i] * kap[j];
     /* three right-hand sides: 0 = residual, 1 = -B_theta, 2 = -B_nu3 */
     double rc[3][7], q[3][7], k0[3];
@@ -336,8 +350,8 @@ static int kkt_solve(const oder *d, work_t *w, const iter_t *it, double mu) {
       }
       ruj = j == 0 ? -w->ru[k] : j == 1 ? -w->gu[k] : 0.0;
       solveAT(s, cs, n, nt);
-      k0[j] = (be * nt[IW] + ruj) / D;
-      for (int i = 0; i < 7; i++) q[j][i] = nt[i] - be * M[i * 7 + IW] * k0[j];
+      k0[j] = (be * nt[IB] + ruj) / D;
+      for (int i = 0; i < 7; i++) q[j][i] = nt[i] - be * M[i * 7 + IB] * k0[j];
       for (int i = 0; i < 7; i++) {
         double a = 0; for (int l = 0; l < 7; l++) a += P[i * 7 + l] * rc[j][l];
         p[j][i] = q[j][i] - a;
@@ -364,9 +378,10 @@ static int kkt_solve(const oder *d, work_t *w, const iter_t *it, double mu) {
     const double *zp = k ? st.z + 7 * (k - 1) : zero, *kap = w->kap + 7 * k;
     double xi[7], azp[7], du = w->kap0[3 * k] + w->kap0[3 * k + 1] * dth + w->kap0[3 * k + 2] * dnu3;
     if (g_scheme == 1 && k > 0) abar_mul((s - 1)->G, cs, zp, azp); else memcpy(azp, zp, 56);
+    if (g_form == 1) azp[IA] = 0.0;
     for (int i = 0; i < 7; i++) { xi[i] = azp[i] - w->c[7 * k + i] + hT * s->F[i] * dth; du -= kap[i] * xi[i]; }
     st.u[k] = du;
-    xi[IW] += be * du;
+    xi[IB] += be * du;
     solveA(s, cs, xi, st.z + 7 * k);
   }
   for (int k = K - 1; k >= 0; k--) {        /* adjoint */
@@ -381,6 +396,7 @@ static int kkt_solve(const oder *d, work_t *w, const iter_t *it, double mu) {
     if (k + 1 < K) {
       double t[7];
       if (g_scheme == 1) abart_mul(s->G, cs, st.lam + 7 * (k + 1), t); else memcpy(t, st.lam + 7 * (k + 1), 56);
+      if (g_form == 1) t[IA] = 0.0;
       for (int i = 0; i < 7; i++) r[i] += t[i];
     }
     solveAT(s, cs, r, st.lam + 7 * k);
@@ -437,7 +453,7 @@ static double kkt_error(const oder *d, work_t *w, const iter_t *it, double mu) {
     step_f(d, z, k ? z - 7 : zero7, it->u[k], ax, ay, F);
     for (int i = 0; i < 7; i++) lt[i] = l[i] + ((g_scheme == 1 && ln) ? ln[i] : 0.0);
     fzt(G, lt, fl);
-    for (int i = 0; i < 7; i++) { r[i] = l[i] - cs * fl[i] - (ln ? ln[i] : 0.0); rth -= hT * F[i] * l[i]; l1 += fabs(l[i]); }
+    for (int i = 0; i < 7; i++) { r[i] = l[i] - cs * fl[i] - ((ln && !(g_form == 1 && i == IA)) ? ln[i] : 0.0); rth -= hT * F[i] * l[i]; l1 += fabs(l[i]); }
     r[IA] += -zb[0] + zb[1]; r[IM] += -zb[2] + zb[3];
     if (k == K - 1) {
       double et = z[IY] + d->rho0, rho = sqrt(z[IX] * z[IX] + et * et);
@@ -447,7 +463,7 @@ static double kkt_error(const oder *d, work_t *w, const iter_t *it, double mu) {
     }
     for (int i = 0; i < 7; i++) rd = fmax(rd, fabs(r[i]));
     double u = it->u[k];
-    rd = fmax(rd, fabs(-dt * d->alpha * l[IW] - zb[4] + zb[5]));
+    rd = fmax(rd, fabs((g_form == 1 ? -0.5 * d->aub * l[IA] : -dt * d->alpha * l[IW]) - zb[4] + zb[5]));
     double lo[3] = {z[IA], z[IM], u + 1.0}, up[3] = {d->aub - z[IA], 1.0 - z[IM], 1.0 - u};
     for (int b = 0; b < 3; b++) {
       comp = fmax(comp, fmax(fabs(lo[b] * zb[2 * b] - mu), fabs(up[b] * zb[2 * b + 1] - mu)));
@@ -473,6 +489,7 @@ static void initial_guess(const oder *d, int K, double h, iter_t *it) {
     z[IX] = fr * xf; z[IY] = fr * yf; z[IVX] = -fr * vp * cos(dr); z[IVY] = -fr * vp * sin(dr);
     z[IA] = fr * aend; z[IW] = aend / (K * dt); z[IM] = d->mrate * dt * (k + 1);
     it->u[k] = 0.0;
+    if (g_form == 1) { z[IW] = 0.0; it->u[k] = z[IA] / (0.5 * d->aub) - 1.0; }
   }
   it->sc[S_TH] = tf0;
 }
@@ -601,6 +618,7 @@ void oracle_accel(const double *params, int n, const double *x, const double *y,
 
 /* equality-constraint values at an iterate blob */
 void oracle_set_scheme(int scheme) { g_scheme = scheme == 1 ? 1 : 0; }
+void oracle_set_formulation(int form) { g_form = form == 1 ? 1 : 0; }
 int oracle_get_scheme(void) { return g_scheme; }
 
 void oracle_constraints(const double *params, int nt, const double *blob, double *c) {

@@ -38,6 +38,12 @@ def set_scheme(scheme: int):
     lib().oracle_set_scheme(int(scheme))
 
 
+def set_formulation(form: int):
+    """0 = current script (u = angledoubledot is the MV), 1 = v1 script (the angle is the MV; embedded in the
+    same state layout, see ascent_oracle.c).  Thread-local in the library."""
+    lib().oracle_set_formulation(int(form))
+
+
 def pack_params(P) -> np.ndarray:
     """Params dataclass (oracle.ascent_numpy.Params) or dict -> 16 doubles."""
     get = (lambda k: P[k]) if isinstance(P, dict) else (lambda k: getattr(P, k))
@@ -52,9 +58,10 @@ def blob_size(nt):
     return lib().oracle_blob_size(nt)
 
 
-def newton_step(params16, nt, blob, mu, delta_w, scheme=0):
+def newton_step(params16, nt, blob, mu, delta_w, scheme=0, formulation=0):
     L = lib()
     L.oracle_set_scheme(int(scheme))
+    L.oracle_set_formulation(int(formulation))
     step = np.zeros_like(blob)
     rc = L.oracle_newton_step(_p(params16), nt, _p(blob), C.c_double(mu), C.c_double(delta_w), _p(step))
     return rc, step
@@ -81,9 +88,10 @@ def accel(params16, x, y, a, m, px, py):
     return ax, ay, gax, gay, H
 
 
-def solve_batch(params, nt=200, max_iter=300, tol=1e-9, guess_blob=None, want_blob=False, scheme=0):
+def solve_batch(params, nt=200, max_iter=300, tol=1e-9, guess_blob=None, want_blob=False, scheme=0, formulation=0):
     """params: (batch,16).  Returns dict(traj (batch,10,nt), tf, status, iters[, blob])."""
     lib().oracle_set_scheme(int(scheme))
+    lib().oracle_set_formulation(int(formulation))
     params = np.ascontiguousarray(np.atleast_2d(params), dtype=np.float64)
     B = params.shape[0]
     traj = np.zeros((B, 10, nt))

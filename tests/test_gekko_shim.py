@@ -20,12 +20,13 @@ def _example():
     return mod
 
 
-def _oracle_solver(P, nt, tol, max_iter, **kw):
+def _oracle_solver(P, nt, tol, max_iter, formulation=0, **kw):
     from oracle import c_oracle
     from lunar_module_ascent_trajectory_optimiser_amd.params import pack
     from lunar_module_ascent_trajectory_optimiser_amd.solver import BatchResult
     P = pack(P)
-    r = c_oracle.solve_batch(P, nt, max_iter, tol)
+    r = c_oracle.solve_batch(P, nt, max_iter, tol, formulation=formulation)
+    c_oracle.set_formulation(0)
     return BatchResult(P, nt, np.ascontiguousarray(np.moveaxis(r["traj"], 0, 2)), r["tf"], r["status"], r["iters"], None, 0.0)
 
 
@@ -116,6 +117,71 @@ def test_reference_script_runs_unmodified_on_the_shim(coracle, golden, tmp_path,
     assert abs(ft - golden["current"]["final_time"]) <= 1e-4 * golden["current"]["final_time"]
     for f in ("takeoff_contextualized.png", "Angle_vs_Time.png", "takeoff_trajectory.png"):
         assert (tmp_path / f).exists()
+
+
+def _build_v1(solver=None):
+    """A v1-style declaration (PDF p26-28 as described in SURVEY.md B.2): the angle is the MV, circular target
+    53108.4 m, mass_scalar 2576 with mflow 5.053/2376.  Written here from that description, not copied."""
+    from lunar_module_ascent_trajectory_optimiser_amd.gekko_shim import GEKKO
+    m = GEKKO(solver=solver)
+    nt = 200
+    m.time = np.linspace(0, 1, nt)
+    m.options.NODES, m.options.IMODE, m.options.SOLVER, m.options.MAX_ITER = 2, 6, 3, 20000
+    tf = m.FV(value=0, lb=0, ub=1); tf.STATUS = 1
+    G, M, R0 = m.Const(6.674e-11, name="G"), m.Const(7.346e22, name="M"), m.Const(1738100, name="R0")
+    Ft, M0 = m.Const(15346, name="Ft"), m.Const(4821, name="M0")
+    S, mS = m.Const(53108.4, name="distance Scale"), m.Const(2576, name="mass Scale")
+    mflow, T = 5.053 / 2376, 470
+    v_orb = (6.674e-11 * 7.346e22 / (1738100 + 53108.4)) ** 0.5
+    mass = m.Var(value=0, lb=0, ub=1, name="mass")
+    y, ydot, ydd = m.Var(value=0, name="y"), m.Var(name="ydot"), m.Var(name="ydoubledot")
+    x, xdot, xdd = m.Var(value=0, name="x"), m.Var(name="xdot"), m.Var(name="xdoubledot")
+    angle = m.MV(name="angle", lb=0, ub=np.pi / 3); angle.STATUS = 1; angle.DCOST = 1e-5
+    for var, rate in ((y, ydot), (ydot, ydd), (x, xdot), (xdot, xdd)):
+        m.Equation(var.dt() == tf * rate * T)
+    m.Equation(mass.dt() == mflow * T * tf)
+    X, Y = x * S, y * S + R0
+    r = (X ** 2 + Y ** 2) ** (1 / 2)
+    m.Equation(ydd == ((Ft / ((M0 - mS * mass) * r)) * (Y * m.cos(3 * angle) + X * m.sin(3 * angle)) - Y * (G * M / r ** 3)) / S)
+    m.Equation(xdd == ((Ft / ((M0 - mS * mass) * r)) * (X * m.cos(3 * angle) - Y * m.sin(3 * angle)) - X * (G * M / r ** 3)) / S)
+    for v in (y, x, ydot, xdot, angle, mass):
+        m.fix(v, pos=0, val=0)
+    c1 = np.full(nt, S + R0 + 1); c1[-1] = 0
+    c2 = np.zeros(nt); c2[-1] = 1
+    p1, p2 = m.Param(value=c1), m.Param(value=c2)
+    m.Equation(((y + R0 / S) ** 2 + x ** 2) ** (1 / 2) + p1 >= (R0 + S) / S)
+    m.Equation(xdot ** 2 + ydot ** 2 >= (v_orb / S) ** 2 * p2)
+    m.Equation((Y * (ydot * S) + X * (xdot * S)) * p2 == 0)
+    m.Minimize(tf)
+    return m, dict(tf=tf, x=x, y=y, xdot=xdot, ydot=ydot, xdd=xdd, ydd=ydd, angle=angle)
+
+
+def _check_v1(v, golden):
+    g, S = golden["v1"], 53108.4
+    assert abs(v["tf"].value[0] - g["tf"]) <= 1e-4 * g["tf"]
+    assert abs(v["tf"].value[0] * 470 - g["final_time"]) <= 1e-4 * g["final_time"]
+    assert abs(-v["x"].value[-1] * S - g["final_x_flipped"]) <= 1e-4 * g["final_x_flipped"]
+    assert abs(v["y"].value[-1] * S - g["final_y"]) <= 1e-4 * g["final_x_flipped"]
+    assert abs(-v["xdot"].value[-1] * S - g["final_xdot_flipped"]) <= 1e-4 * g["final_xdot_flipped"]
+    assert abs(v["ydd"].value[-1] * S - g["final_ydoubledot"]) <= 2e-3 * abs(g["final_ydoubledot"])
+    ang = 3 * np.asarray(v["angle"].value) * 180 / np.pi
+    assert 33 < ang[1] < 37 and 109 < ang[-1] < 113
+
+
+def test_v1_style_script_on_the_shim_with_oracle_solver(coracle, golden):
+    """The second golden vector (PDF p30) through the same front door."""
+    m, v = _build_v1(solver=_oracle_solver)
+    P, R, tf = m._extract()
+    assert m._formulation == 1 and P.mass_scalar == 2576 and P.r_apo == pytest.approx(P.r_peri, rel=1e-9)
+    m.solve(disp=False)
+    _check_v1(v, golden)
+
+
+@pytest.mark.gpu
+def test_v1_style_script_end_to_end_on_gpu(golden):
+    m, v = _build_v1()
+    m.solve(disp=False)
+    _check_v1(v, golden)
 
 
 @pytest.mark.gpu

@@ -227,3 +227,30 @@ def test_trapezoid_scheme_matches_oracle(coracle):
     assert np.abs(rb.tf - refb["tf"]).max() <= 1e-9 * refb["tf"].max()
     # second order vs first order: the trapezoid answer is the mesh-converged one (Richardson of backward Euler)
     assert abs(rb.final_time()[0] - A.solve_batch(S[:1], 400, tol=1e-9, scheme=1).final_time()[0]) < 0.01
+
+
+def test_v1_formulation_matches_second_golden_vector(coracle, golden):
+    """formulation=1: the v1 script of the PDF appendix (p26-28; the angle itself is the MV, circular target,
+    mass_scalar 2576 with mflow 5.053/2376).  Second golden vector: the numbers printed on PDF p30."""
+    P = A.AscentParams(r_peri=53108.4, r_apo=53108.4, mass_scalar=2576.0)
+    r = A.solve_batch(P, NT, tol=1e-9, formulation="v1", max_iter=500)
+    assert r.status[0] == 0
+    g, S = golden["v1"], 53108.4
+    assert abs(r.final_time()[0] - g["final_time"]) <= 1e-4 * g["final_time"]
+    assert abs(r.tf[0] - g["tf"]) <= 1e-4 * g["tf"]
+    tr = r.traj[:, :, 0]
+    assert abs(-tr[0, -1] * S - g["final_x_flipped"]) <= 1e-4 * g["final_x_flipped"]        # the v1 prints flip x
+    assert abs(tr[1, -1] * S - g["final_y"]) <= 1e-4 * g["final_x_flipped"]
+    assert abs(-tr[2, -1] * S - g["final_xdot_flipped"]) <= 1e-4 * g["final_xdot_flipped"]
+    assert abs(tr[3, -1] * S - g["final_ydot"]) <= 1e-4 * g["final_xdot_flipped"]
+    assert abs(-tr[4, -1] * S - g["final_xdoubledot_flipped"]) <= 2e-3 * g["final_xdoubledot_flipped"]
+    ang = 3 * tr[6] * 180 / np.pi
+    assert 33 < ang[1] < 37 and 109 < ang[-1] < 113 and np.abs(tr[7]).max() == 0.0    # PDF p21,31 plot facts
+    # against the oracle in the same embedding, and a small sweep
+    ref = coracle.solve_batch(P.as_row()[None], NT, 500, 1e-9, formulation=1)
+    assert abs(r.tf[0] - ref["tf"][0]) <= 1e-9 * ref["tf"][0] and r.iters[0] == ref["iters"][0]
+    S8 = A.sweep_isp_drymass(3, 3, base=P)
+    rb = A.solve_batch(S8, NT, tol=1e-9, formulation=1, max_iter=500)
+    refb = coracle.solve_batch(S8, NT, 500, 1e-9, formulation=1)
+    coracle.set_formulation(0)
+    assert np.all(rb.status == 0) and np.abs(rb.tf - refb["tf"]).max() <= 1e-9 * refb["tf"].max()

@@ -243,3 +243,21 @@ def test_trapezoid_newton_step_matches_generic_sparse_lu(coracle):
     assert np.abs(step[:7 * K] - dW[:, :7].ravel()).max() < 1e-8 * max(1.0, np.abs(dx).max())
     assert np.abs(step[8 * K:15 * K] - dlam[:7 * K]).max() < 1e-8 * max(1.0, np.abs(dlam).max())
     assert abs(step[21 * K] - dx[nlp.itf]) < 1e-9
+
+
+def test_c_oracle_v1_embedding_matches_numpy_v1_and_golden(coracle, golden):
+    """The C oracle carries the v1 script in its 7-slot state (angle row algebraic, angle = (ub/2)(u+1)); the
+    numpy oracle restates v1 natively with 5 states and the angle as the control.  Same optimum."""
+    P = v1_params()
+    p16 = coracle.pack_params(P)
+    r = coracle.solve_batch(p16[None], 200, 500, 1e-9, formulation=1)
+    coracle.set_formulation(0)
+    assert r["status"][0] == 0
+    assert abs(r["tf"][0] * 470 - golden["v1"]["final_time"]) <= 1e-4 * golden["v1"]["final_time"]
+    nlp = AscentNLP(P, 200, 1)
+    v, _, info = solve_ip(nlp, tol=1e-9, max_iter=400)
+    assert info["status"] == "converged"
+    assert abs(v[nlp.itf] - r["tf"][0]) <= 1e-10 * r["tf"][0]
+    o = nlp.outputs(v)
+    assert np.abs(o["x"] - r["traj"][0][0]).max() < 1e-7 and np.abs(o["angle"][1:] - r["traj"][0][6][1:]).max() < 1e-7
+    assert np.abs(r["traj"][0][7]).max() == 0.0                       # angledot slot stays zero
