@@ -501,6 +501,11 @@ static double push(double v, double lb, double ub) {
 
 enum { ST_CONVERGED = 0, ST_MAXITER = 1, ST_LINESEARCH = 2, ST_REGULARISATION = 3 };
 
+/* barrier schedule (Waechter & Biegler 2006 defaults: mu0 0.1, kappa_eps 10, kappa_mu 0.2, theta_mu 1.5);
+ * oracle_set_barrier_schedule exists for experiments only -- the product uses the defaults */
+static double g_mu0 = 0.1, g_keps = 10.0, g_kmu = 0.2, g_thmu = 1.5;
+void oracle_set_barrier_schedule(double mu0, double keps, double kmu, double thmu) { g_mu0 = mu0; g_keps = keps; g_kmu = kmu; g_thmu = thmu; }
+
 /* one NLP.  blob: in = initial guess (primal part used) if use_guess, out = solution iterate. */
 static int solve_one(const oparams *prm, int nt, int max_iter, double tol, int use_guess, double *blob,
                      int *iters_out, int *nreg_out) {
@@ -520,13 +525,13 @@ static int solve_one(const oparams *prm, int nt, int max_iter, double tol, int u
   it.sc[S_S1] = fmax(it.sc[S_S1], 1e-2); it.sc[S_S2] = fmax(it.sc[S_S2], 1e-2);
   it.sc[S_ZLT] = it.sc[S_ZUT] = it.sc[S_ZS1] = it.sc[S_ZS2] = 1.0;
   memset(it.lam, 0, 7 * K * 8); it.sc[S_NU3] = it.sc[S_NU1] = it.sc[S_NU2] = 0.0;
-  double mu = 0.1, nu_pen = 1.0, dw_last = 0.0;
+  double mu = g_mu0, nu_pen = 1.0, dw_last = 0.0;
   int status = ST_MAXITER, iters = 0, nreg = 0;
   for (int iter = 0; iter < max_iter; iter++) {
     double e0 = kkt_error(&d, w, &it, 0.0);
     if (e0 <= tol) { status = ST_CONVERGED; break; }
-    while (mu > tol / 10.0 && kkt_error(&d, w, &it, mu) <= 10.0 * mu) {
-      mu = fmax(tol / 10.0, fmin(0.2 * mu, pow(mu, 1.5)));
+    while (mu > tol / 10.0 && kkt_error(&d, w, &it, mu) <= g_keps * mu) {
+      mu = fmax(tol / 10.0, fmin(g_kmu * mu, pow(mu, g_thmu)));
       nu_pen = 1.0;
     }
     double dw = 0.0; int fail = 0;
