@@ -1034,31 +1034,35 @@ int pipeline_run(const ascent_params *dp, long batch, int K, int scheme, int for
   PCHK(hipGetLastError());
   // Each round advances every lane by one stage of its own state machine: a lane in its normal flow
   // completes one interior-point iteration per round; a rejected line-search trial or a wrong-inertia
-  // factorisation costs that lane (only) one more round.  A lane needs at most max_iter+1 accepted trial
-  // points plus <= 40 rejected trials and ~50 refactorisations per iteration, so the loop terminates.
-  for (long round = 0;; round++) {
-    if (round > 100L * (max_iter + 2)) { snprintf(err, errlen, "pipeline did not terminate"); return ASCENT_E_HIP; }
+  // factorisation costs that lane (only) one more round.  Every kernel is guarded by the lanes' states, so a
+  // round enqueued for lanes that turn out to have nothing to do is harmless: the host therefore enqueues
+  // `burst` rounds back to back and reads the counters of the last one only then -- the device never waits
+  // for the host inside a burst.  A lane needs at most max_iter+1 accepted trial points plus a bounded number
+  // of rejected trials and refactorisations per iteration, so the loop terminates.
+  int burst = 4;
+  if (const char *e = getenv("ASCENT_ROUNDS_PER_SYNC")) { const int v = atoi(e); if (v >= 1 && v <= 64) burst = v; }
 #define ASC_LAUNCH(KERNEL, GRID, ...)                                                                               \
   do {                                                                                                              \
     if (form == 1) hipLaunchKernelGGL((KERNEL<0, 1>), GRID, dim3(WAVE), 0, stream, __VA_ARGS__);                    \
     else if (scheme == 1) hipLaunchKernelGGL((KERNEL<1, 0>), GRID, dim3(WAVE), 0, stream, __VA_ARGS__);            \
     else hipLaunchKernelGGL((KERNEL<0, 0>), GRID, dim3(WAVE), 0, stream, __VA_ARGS__);                              \
   } while (0)
-    ASC_LAUNCH(q_trial_eval, dim3(tiles, g.nch), dp, batch, g, ws);
-    PCHK(hipMemsetAsync(counters, 0, 3 * sizeof(int), stream));
-    ASC_LAUNCH(q_decide_factor, dim3(tiles), dp, batch, g, ws, max_iter, tol, counters);
-    PCHK(hipMemcpyAsync(host_cnt, counters, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
-    launches += 2;
-    PCHK(hipStreamSynchronize(stream));
-    const int n_pending = host_cnt[0], n_factored = host_cnt[1];   // retrial/refactor lanes; lanes with a step to take
-    if (debug) fprintf(stderr, "[ascent pipeline] round %ld: pending %d (refactor %d), stepping %d\n", round, n_pending, host_cnt[2], n_factored);
-    if (n_pending == 0 && n_factored == 0) break;
-    if (n_factored > 0) {
+  for (long round = 0;;) {
+    if (round > 100L * (max_iter + 2)) { snprintf(err, errlen, "pipeline did not terminate"); return ASCENT_E_HIP; }
+    for (int r = 0; r < burst; r++, round++) {
+      ASC_LAUNCH(q_trial_eval, dim3(tiles, g.nch), dp, batch, g, ws);
+      PCHK(hipMemsetAsync(counters, 0, 3 * sizeof(int), stream));
+      ASC_LAUNCH(q_decide_factor, dim3(tiles), dp, batch, g, ws, max_iter, tol, counters);
+      if (r == burst - 1) PCHK(hipMemcpyAsync(host_cnt, counters, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
       ASC_LAUNCH(q_forward, dim3(tiles), dp, batch, g, ws);
       hipLaunchKernelGGL(q_local, dim3(tiles, g.nch), dim3(WAVE), 0, stream, dp, batch, g, ws);
       ASC_LAUNCH(q_adjoint, dim3(tiles), dp, batch, g, ws);
-      launches += 3;
+      launches += 5;
     }
+    PCHK(hipStreamSynchronize(stream));
+    const int n_pending = host_cnt[0], n_factored = host_cnt[1];   // retrial/refactor lanes; lanes with a step to take
+    if (debug) fprintf(stderr, "[ascent pipeline] after round %ld: pending %d (refactor %d), stepping %d\n", round - 1, n_pending, host_cnt[2], n_factored);
+    if (n_pending == 0 && n_factored == 0) break;
   }
   hipLaunchKernelGGL(q_finish, dim3(tiles), dim3(WAVE), 0, stream, dp, batch, g, ws, dtraj, dtf, dstatus, diters,
                      dblob, getenv("ASCENT_DEBUG_ROUNDS") != nullptr);
