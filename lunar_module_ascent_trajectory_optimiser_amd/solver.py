@@ -60,6 +60,23 @@ class BatchResult:
         """seconds: tf.value[0]*final_time (Launch_Optimiser.py:194)."""
         return self.tf * self.params[:, 11]
 
+    def orbit(self) -> dict:
+        """Kepler-exact two-body orbit through every problem's final state (the reference's
+        v1 script propagated the end state with explicit Euler, PDF p28-29; this is the closed form).  Returns
+        periapsis / apoapsis altitudes above R0 (m), semi-major axis (m), eccentricity and flight-path angle (rad).
+        Note for the reference's own target: it asks for the circular speed of the *mean* radius at the
+        17.7 km insertion altitude (Launch_Optimiser.py:72-78), which is below the local circular speed."""
+        P = self.params
+        S, R0, GM = P[:, 9], P[:, 2], P[:, 0] * P[:, 1]
+        X, Y = self.traj[0, -1] * S, self.traj[1, -1] * S + R0
+        VX, VY = self.traj[2, -1] * S, self.traj[3, -1] * S
+        r, v2 = np.hypot(X, Y), VX * VX + VY * VY
+        a = 1.0 / (2.0 / r - v2 / GM)
+        h = X * VY - Y * VX
+        e = np.sqrt(np.maximum(0.0, 1.0 - h * h / (GM * a)))
+        return dict(periapsis_alt=a * (1 - e) - R0, apoapsis_alt=a * (1 + e) - R0, semi_major_axis=a, eccentricity=e,
+                    flight_path_angle=np.arcsin(np.clip((X * VX + Y * VY) / (r * np.sqrt(v2)), -1, 1)))
+
     def outputs(self, i: int = 0) -> dict:
         """The quantities the reference prints/plots for problem i (Launch_Optimiser.py:178-202):
         physical t, x_pos (sign flipped as :200), y_pos (:201), theta in degrees (:202), mass, and

@@ -254,3 +254,17 @@ def test_v1_formulation_matches_second_golden_vector(coracle, golden):
     refb = coracle.solve_batch(S8, NT, 500, 1e-9, formulation=1)
     coracle.set_formulation(0)
     assert np.all(rb.status == 0) and np.abs(rb.tf - refb["tf"]).max() <= 1e-9 * refb["tf"].max()
+
+
+def test_orbit_of_the_insertion_state(nominal_gpu):
+    """Kepler-exact orbit of the final state.  The reference targets the circular speed of the mean radius
+    (1654.40 m/s, Launch_Optimiser.py:72-78) at 17.7 km altitude with r.v = 0; the local circular speed there is
+    1671.0 m/s, so the modelled insertion point is the APOAPSIS of the resulting two-body orbit (the 87 x 17 km
+    ellipse would need 1687.5 m/s).  The restatement reproduces that property of the reference faithfully."""
+    o = nominal_gpu.orbit()
+    assert abs(o["apoapsis_alt"][0] - 17703.0) < 1.0            # insertion altitude, r.v = 0
+    assert abs(o["flight_path_angle"][0]) < 1e-9
+    mu, r = 6.674e-11 * 7.346e22, 1738100.0 + 17703.0
+    a = 1.0 / (2.0 / r - 1654.3956154295 ** 2 / mu)
+    assert abs(o["semi_major_axis"][0] - a) < 1.0
+    assert o["periapsis_alt"][0] < 0                             # below the surface: v < local circular speed
