@@ -432,7 +432,8 @@ ASC_DEV void loadQV(const QTile &t_, int k, InQV &in) {
 
 template <int SCHEME, int FORM>
 __global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *params, long batch, Geo g,
-                                                        double *ws, int max_iter, double tol, int *counters) {
+                                                        double *ws, int max_iter, double tol, int *counters,
+                                                        int factor_here) {
   const long p = (long)blockIdx.x * WAVE + threadIdx.x;
   if (p >= batch) return;
   const QTile t_((gdbl *)ws + (size_t)blockIdx.x * g.tile_doubles());
@@ -518,6 +519,10 @@ __global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *par
     state = ST_FACTOR;
   } else if (state == ST_FACTORED) {
     atomicAdd(&counters[1], 1);
+    return;
+  }
+  if (!factor_here) {   // q_factor_wide follows and factorises the lanes left in ST_FACTOR
+    SC(X_STATE) = ST_FACTOR;
     return;
   }
   // ---- backward factorisation at the current iterate, primal regularisation dw ---------------------
@@ -685,6 +690,245 @@ __global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *par
     SC(X_STATE) = ST_FACTORED;
     atomicAdd(&counters[1], 1);
   } else {   // wrong inertia: raise the primal regularisation; factorised again in the next round
+    const double dwl = SC(X_DWL);
+    const double ndw = dw == 0.0 ? fmax(1e-4, dwl / 3.0) : dw * 8.0;
+    if (ndw > 1e10) {
+      SC(X_STATUS) = ASCENT_REGULARISATION_FAILED; SC(X_STATE) = ST_DONE;
+    } else {
+      SC(X_DW) = ndw; SC(X_STATE) = ST_FACTOR;
+      atomicAdd(&counters[0], 1);
+      atomicAdd(&counters[2], 1);
+    }
+  }
+}
+
+// ==============================================================================================
+// q_factor_wide: the backward factorisation with 16 lanes per NLP
+// ==============================================================================================
+// q_decide_factor gives every NLP one lane: 64 wavefronts for 4096 NLPs, each issuing ~1100 FP64 instructions
+// per step, on a chip with 1024 SIMDs.  Here an NLP owns a row of 16 lanes (the DPP row of gfx950): lanes 0-6
+// hold one column each of the 7x7 value-function matrix P, lanes 7-9 the three right-hand-side vectors, so the
+// same instruction stream -- gather the node's terms, v <- A^-T v, pivot update v -= mw * coef -- advances all
+// ten vectors at once.  N <- A^-T N A^-1 is two column-wise A^-T solves with a 7x7 transpose through LDS in
+// between; the pivot column is handed round with DPP row broadcasts; P*rc comes from column dot products (P is
+// symmetric) moved to the right-hand-side lanes through LDS.  One wavefront = 4 NLPs, one workgroup = 4
+// wavefronts = 16 NLPs (a quarter tile: every 512-byte workspace row is read as four 128-byte pieces).
+// ~4x fewer instructions per step on the critical path, 16x more wavefronts.  Backward Euler only.
+constexpr int WIDE_NLP_PER_BLOCK = 16, WIDE_THREADS = 256;
+
+template <int SRC>
+ASC_DEV double bcast16(double v) {   // lane SRC of this lane's row of 16, to the whole row (v_mov_b64_dpp row_newbcast)
+  const long x = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(long, v), 0x150 + SRC, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, x);
+}
+
+// One step record as a wavefront of q_factor_wide loads it: 7 gathers private to the lane's vector, and two in
+// which the 16 lanes of an NLP fetch 16 different rows that all of them need (G, E, R0, ru0, bu, bza | c, F,
+// bzm) and then hand round with row broadcasts -- 9 loads per step instead of 40 (the path from L1 to the
+// registers, shared by the four wavefronts of a CU, is what the replicated loads saturated).
+struct InW {
+  double gq[7], gA, gB;
+};
+
+template <int FORM>
+__global__ __launch_bounds__(WIDE_THREADS) void q_factor_wide(const ascent_params *params, long batch, Geo g,
+                                                              double *ws, int *counters) {
+  __shared__ double lds_t[WIDE_THREADS / 16][7][7];     // [group][column][row]
+  __shared__ double lds_d[WIDE_THREADS / 16][2][8];     // [group][rhs][row]
+  const int grp = threadIdx.x >> 4, role = threadIdx.x & 15;
+  const long p = (long)blockIdx.x * WIDE_NLP_PER_BLOCK + grp;
+  const unsigned L = (unsigned)(p & (WAVE - 1));
+  const QTile t_((gdbl *)ws + (size_t)(blockIdx.x >> 2) * g.tile_doubles(), L);
+  gdbl *sc = scal_base(t_, g);
+  if (p >= batch || (int)SC(X_STATE) != ST_FACTOR) return;
+  const Der d = derive(params[p]);
+  const int K = g.K;
+  const double mu = SC(X_MU);
+  const unsigned oc = L + (unsigned)((int)SC(X_CUR)) * (21 * WAVE);
+  const Scal s = load_scal(t_, sc, X_S);
+  const double dw = SC(X_DW);
+  const double hT = (1.0 / K) * d.T, dt = hT * s.th, be = dt * d.alpha, ith = rcp(s.th);
+  const double cs = dt;
+  constexpr int IB = FORM == 1 ? IA : IW;
+  const double bu = FORM == 1 ? 0.5 * d.aub : be;
+  const bool col = role < 7, rhs = role >= 7 && role < 10;
+  // what this lane gathers from a step record for row i of its vector, and with which sign
+  unsigned goff[7];
+  double gsc[7];
+  {
+    constexpr int hmap[7] = {0, 1, -1, -1, 2, -1, 3};   // position of a state among (x, y, angle, mass)
+    constexpr int hrow[4][4] = {{0, 1, 2, 3}, {1, 4, 5, 6}, {2, 5, 7, 8}, {3, 6, 8, 9}};
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) {
+      int row = Q_H; double sgn = 0.0;
+      if (col) {
+        ASC_UNROLL
+        for (int c = 0; c < 7; c++)
+          if (c == role && hmap[i] >= 0 && hmap[c] >= 0) { row = Q_H + hrow[hmap[i]][hmap[c]]; sgn = 1.0; }
+      } else if (role == 7) { row = Q_RZ + i; sgn = -1.0; }
+      else if (role == 8) { row = Q_GT + i; sgn = -1.0; }
+      goff[i] = (unsigned)row * WAVE + L;
+      gsc[i] = sgn;
+    }
+  }
+  const double bsc = role == 7 ? -mu : 0.0;           // barrier terms of the residual right-hand side
+  const int rowA = role < 8 ? Q_G + role : role < 12 ? Q_E + role - 8 : role == 12 ? Q_SC : role == 13 ? Q_SC + 1
+                   : role == 14 ? Q_SC + 4 : Q_SC + 2;
+  const int rowB = role < 7 ? Q_C + role : role < 14 ? Q_F + role - 7 : role == 14 ? Q_SC + 3 : Q_SC;
+  const unsigned offA = (unsigned)rowA * WAVE + L, offB = (unsigned)rowB * WAVE + L;
+  auto loadW = [&](int k, InW &in) __attribute__((always_inline)) {
+#ifdef WIDE_FAKE
+    const gdbl *sp = t_.st(k & 3);
+#else
+    const gdbl *sp = t_.st(k);
+#endif
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) in.gq[i] = sp[goff[i]];
+    in.gA = sp[offA];
+    in.gB = sp[offB];
+  };
+  double a[7];
+  ASC_UNROLL
+  for (int i = 0; i < 7; i++) a[i] = 0.0;
+  double U = 0.0, V = 0.0, k10 = 0.0, k11 = 0.0, k12 = 0.0, k20 = 0.0, k22 = 0.0;
+  int bad = 0;
+  // terminal node: Hessian of the terminal Lagrangian + slack-eliminated barrier terms (column lanes), the
+  // terminal parts of the right-hand sides (lanes 7 and 9)
+  double zK[7];
+  ldo<7>(t_.st(K - 1), Q_IT + O_Z, oc, zK);
+  const Terminal tm = terminal_eval(d, zK);
+  const double is1 = rcp(s.s1), is2 = rcp(s.s2);
+  const double sig1 = s.zs1 * is1 + dw, sig2 = s.zs2 * is2 + dw;
+  const double rs1 = -mu * is1 - s.nu1, rs2 = -mu * is2 - s.nu2;
+  {
+    const double cg1 = tm.g1 - s.s1, cg2 = tm.g2 - s.s2;
+    double Qt[28];
+    ASC_UNROLL
+    for (int i = 0; i < 28; i++) Qt[i] = 0.0;
+    terminal_hessian(Qt, tm, s.nu3, s.nu1, s.nu2, sig1, sig2);
+    const double w1 = s.nu1 + sig1 * cg1 + rs1, w2 = s.nu2 + sig2 * cg2 + rs2;
+    const double r0[4] = {s.nu3 * tm.e3g[0] + w1 * tm.g1g[0], s.nu3 * tm.e3g[1] + w1 * tm.g1g[1],
+                          s.nu3 * tm.e3g[2] + w2 * tm.g2g[0], s.nu3 * tm.e3g[3] + w2 * tm.g2g[1]};
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) {
+      double v = 0.0;
+      ASC_UNROLL
+      for (int c = 0; c < 7; c++) v = role == c ? Qt[sid(i, c)] : v;
+      if (i < 4) { v = role == 7 ? -r0[i] : v; v = role == 9 ? -tm.e3g[i] : v; }
+      a[i] = v;
+    }
+  }
+  auto body = [&](InW &in, int k) __attribute__((always_inline)) {
+    gdbl *sp = t_.st(k);
+    if (FORM == 1 && k < K - 1) {     // step k+1 does not see angle_k: drop its row and column
+      a[IA] = 0.0;
+      if (role == IA) {
+        ASC_UNROLL
+        for (int i = 0; i < 7; i++) a[i] = 0.0;
+      }
+    }
+    const double G[8] = {bcast16<0>(in.gA), bcast16<1>(in.gA), bcast16<2>(in.gA), bcast16<3>(in.gA),
+                         bcast16<4>(in.gA), bcast16<5>(in.gA), bcast16<6>(in.gA), bcast16<7>(in.gA)};
+    const double E[4] = {bcast16<8>(in.gA), bcast16<9>(in.gA), bcast16<10>(in.gA), bcast16<11>(in.gA)};
+    const double R0 = bcast16<12>(in.gA), ru0 = bcast16<13>(in.gA), bur = bcast16<14>(in.gA);
+    const double bza = bcast16<15>(in.gA), bzm = bcast16<14>(in.gB);
+    const double cc[7] = {bcast16<0>(in.gB), bcast16<1>(in.gB), bcast16<2>(in.gB), bcast16<3>(in.gB),
+                          bcast16<4>(in.gB), bcast16<5>(in.gB), bcast16<6>(in.gB)};
+    const double rc1[7] = {hT * bcast16<7>(in.gB), hT * bcast16<8>(in.gB), hT * bcast16<9>(in.gB),
+                           hT * bcast16<10>(in.gB), hT * bcast16<11>(in.gB), hT * bcast16<12>(in.gB),
+                           hT * bcast16<13>(in.gB)};
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) a[i] += gsc[i] * in.gq[i];
+    a[IA] += bsc * bza;
+    a[IM] += bsc * bzm;
+    if (dw != 0.0) {
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) a[i] += role == i ? dw : 0.0;
+    }
+    double b[7];
+    solveAT<FORM>(G, E, cs, a, b);                       // columns of T = A^-T N ; nt = A^-T n on lanes 7-9
+    if (col) {
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) lds_t[grp][role][i] = b[i];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (col) {
+      double t[7];
+      ASC_UNROLL
+      for (int l = 0; l < 7; l++) t[l] = lds_t[grp][l][role];   // row `role` of T = column of T'
+      solveAT<FORM>(G, E, cs, t, b);                     // M = A^-T T'
+    }
+    double mw[7];
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) mw[i] = bu * bcast16<IB>(b[i]);
+    const double D = R0 + dw + bu * mw[IB];
+    if (!(D > 0.0)) bad = 1;
+    const double iD = rcp(D);
+    const double ru = ru0 + mu * bur, gu = FORM == 1 ? 0.0 : ru0 * ith;
+    const double rsel = role == 7 ? ru : role == 8 ? gu : 0.0;
+    const double coef = (bu * b[IB] - rsel) * iD;        // kap_c on column lanes, k0_j on lanes 7-9
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) a[i] = b[i] - mw[i] * coef;   // P column / q_j
+    if (role < 10) sp[(unsigned)(role < 7 ? Q_KA + role : Q_K0 + role - 7) * WAVE + L] = coef;
+    // P rc_0, P rc_1 (rc_0 = -c, rc_1 = hT F, rc_2 = 0): by symmetry element c is the dot product with column c
+    if (col) {
+      double d0 = 0.0, d1 = 0.0;
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) { d0 -= a[i] * cc[i]; d1 += a[i] * rc1[i]; }
+      lds_d[grp][0][role] = d0;
+      lds_d[grp][1][role] = d1;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (rhs) {
+      double prc[7];
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) prc[i] = role == 9 ? 0.0 : lds_d[grp][role == 8 ? 1 : 0][i];
+      double u = 0.0, v = 0.0;
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) {
+        const double pj = a[i] - prc[i], sj = a[i] + pj;
+        u += rc1[i] * sj; v += cc[i] * sj;
+        a[i] = pj;
+      }
+      U += u; V += v;
+    }
+    const double k00 = bcast16<7>(coef), k01 = bcast16<8>(coef), k02 = bcast16<9>(coef);
+    const double Dk1 = D * k01, Dk2 = D * k02;
+    k10 += Dk1 * k00; k11 += Dk1 * k01; k12 += Dk1 * k02; k20 += Dk2 * k00; k22 += Dk2 * k02;
+  };
+#define LD_(k_, buf_) loadW(k_, buf_)
+  ASC_SWEEP_BACKWARD4(InW, LD_, body)
+#undef LD_
+  const double U0 = bcast16<7>(U), U1 = bcast16<8>(U), V1 = bcast16<8>(V), U2 = bcast16<9>(U), V2 = bcast16<9>(V);
+  if (role != 0) return;
+  const double S10 = k10 + 0.5 * (U0 - V1), S11 = k11 + U1, S12 = k12 + 0.5 * U2, S20 = k20 - 0.5 * V2, S22 = k22;
+  int ok = !bad;
+  double dth = 0.0, dnu3 = 0.0;
+  if (ok) {
+    const double itl = rcp(s.th - d.tlb), itu = rcp(d.tub - s.th);
+    const double rthp = SC(X_RTH) + mu * (itu - itl);
+    const double sth = s.zlt * itl + s.zut * itu + dw;
+    const double a11 = sth - S11, a12 = -S12, a22 = -S22;
+    const double b1 = -rthp + S10, b2 = -tm.e3 + S20;
+    const double det = a11 * a22 - a12 * a12;
+    if (det < 0.0) {
+      const double idet = 1.0 / det;
+      dth = (b1 * a22 - a12 * b2) * idet;
+      dnu3 = (a11 * b2 - a12 * b1) * idet;
+    } else {
+      ok = 0;
+    }
+  }
+  if (ok) {
+    SC(X_DTH) = dth; SC(X_DNU3) = dnu3; SC(X_SIG1) = sig1; SC(X_SIG2) = sig2; SC(X_RS1) = rs1; SC(X_RS2) = rs2;
+    SC(X_DWL) = dw;
+    SC(X_STATE) = ST_FACTORED;
+    atomicAdd(&counters[1], 1);
+  } else {
     const double dwl = SC(X_DWL);
     const double ndw = dw == 0.0 ? fmax(1e-4, dwl / 3.0) : dw * 8.0;
     if (ndw > 1e10) {
@@ -945,6 +1189,194 @@ __global__ __launch_bounds__(WAVE) void q_adjoint(const ascent_params *params, l
 }
 
 // ==============================================================================================
+// q_forward_wide / q_adjoint_wide: the two substitution sweeps with 16 lanes per NLP
+// ==============================================================================================
+// The substitutions are short vector recurrences whose cost is fetching ~30 rows per step: with one lane per NLP
+// that is ~30 load instructions per step and a wavefront cannot keep more than 64 in flight.  Here the 16 lanes
+// of an NLP fetch 16 different rows with one gather, hand them round with row broadcasts and all compute the
+// (tiny) step redundantly; lane i stores element i.  Backward Euler only.
+struct InV {
+  double gA, gB, gC;
+};
+// v[role] without dynamic register indexing (which the compiler lowers to scratch memory): a dot product with
+// the lane's one-hot mask, kept in registers for the whole sweep
+template <int N>
+struct OneHot {
+  double m[N];
+  ASC_DEV explicit OneHot(int role) {
+    ASC_UNROLL
+    for (int i = 0; i < N; i++) m[i] = role == i ? 1.0 : 0.0;
+  }
+  ASC_DEV double pick(const double *v) const {
+    double r = m[0] * v[0];
+    ASC_UNROLL
+    for (int i = 1; i < N; i++) r += m[i] * v[i];
+    return r;
+  }
+};
+
+template <int FORM>
+__global__ __launch_bounds__(WIDE_THREADS) void q_forward_wide(const ascent_params *params, long batch, Geo g,
+                                                               double *ws) {
+  const int grp = threadIdx.x >> 4, role = threadIdx.x & 15;
+  const long p = (long)blockIdx.x * WIDE_NLP_PER_BLOCK + grp;
+  const unsigned L = (unsigned)(p & (WAVE - 1));
+  const QTile t_((gdbl *)ws + (size_t)(blockIdx.x >> 2) * g.tile_doubles(), L);
+  gdbl *sc = scal_base(t_, g);
+  if (p >= batch || (int)SC(X_STATE) != ST_FACTORED) return;
+  const Der d = derive(params[p]);
+  const int K = g.K;
+  const double th = SC(X_S + S_TH), dth = SC(X_DTH), dnu3 = SC(X_DNU3);
+  const double hT = (1.0 / K) * d.T, dt = hT * th, be = dt * d.alpha, cs = dt;
+  const int rowA = role < 8 ? Q_G + role : role < 12 ? Q_E + role - 8 : role < 15 ? Q_K0 + role - 12 : Q_G;
+  const int rowB = role < 7 ? Q_C + role : role < 14 ? Q_F + role - 7 : Q_C;
+  const int rowC = role < 7 ? Q_KA + role : Q_KA;
+  const unsigned offA = (unsigned)rowA * WAVE + L, offB = (unsigned)rowB * WAVE + L, offC = (unsigned)rowC * WAVE + L;
+  const unsigned offS = (unsigned)(Q_ST + (role < 8 ? role : 0)) * WAVE + L;     // dz[0..6], du are rows Q_ST + 0..7
+  const OneHot<8> hot(role);
+  double dzp[7];
+  ASC_UNROLL
+  for (int i = 0; i < 7; i++) dzp[i] = 0.0;
+  auto loadV = [&](int k, InV &in) __attribute__((always_inline)) {
+#ifdef WIDE_FAKE
+    const gdbl *sp = t_.st(k & 3);
+#else
+    const gdbl *sp = t_.st(k);
+#endif
+    in.gA = sp[offA]; in.gB = sp[offB]; in.gC = sp[offC];
+  };
+  auto body = [&](InV &in, int k) __attribute__((always_inline)) {
+    gdbl *sp = t_.st(k);
+    const double G[8] = {bcast16<0>(in.gA), bcast16<1>(in.gA), bcast16<2>(in.gA), bcast16<3>(in.gA),
+                         bcast16<4>(in.gA), bcast16<5>(in.gA), bcast16<6>(in.gA), bcast16<7>(in.gA)};
+    const double E[4] = {bcast16<8>(in.gA), bcast16<9>(in.gA), bcast16<10>(in.gA), bcast16<11>(in.gA)};
+    const double k0[3] = {bcast16<12>(in.gA), bcast16<13>(in.gA), bcast16<14>(in.gA)};
+    const double cc[7] = {bcast16<0>(in.gB), bcast16<1>(in.gB), bcast16<2>(in.gB), bcast16<3>(in.gB),
+                          bcast16<4>(in.gB), bcast16<5>(in.gB), bcast16<6>(in.gB)};
+    const double F[7] = {bcast16<7>(in.gB), bcast16<8>(in.gB), bcast16<9>(in.gB), bcast16<10>(in.gB),
+                         bcast16<11>(in.gB), bcast16<12>(in.gB), bcast16<13>(in.gB)};
+    const double ka[7] = {bcast16<0>(in.gC), bcast16<1>(in.gC), bcast16<2>(in.gC), bcast16<3>(in.gC),
+                          bcast16<4>(in.gC), bcast16<5>(in.gC), bcast16<6>(in.gC)};
+    double xi[7], dz[8];
+    double du = k0[0] + k0[1] * dth + k0[2] * dnu3;
+    if (FORM == 1) dzp[IA] = 0.0;     // the angle row has no coupling to the previous angle
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) {
+      xi[i] = dzp[i] - cc[i] + hT * F[i] * dth;
+      du -= ka[i] * xi[i];
+    }
+    if (FORM == 1) xi[IA] += 0.5 * d.aub * du; else xi[IW] += be * du;
+    solveA<FORM>(G, E, cs, xi, dz);
+    dz[7] = du;
+    if (role < 8) sp[offS] = hot.pick(dz);
+    cpy<7>(dzp, dz);
+  };
+#define LD_(k_, buf_) loadV(k_, buf_)
+  ASC_SWEEP_FORWARD4(InV, LD_, body)
+#undef LD_
+}
+
+template <int FORM>
+__global__ __launch_bounds__(WIDE_THREADS) void q_adjoint_wide(const ascent_params *params, long batch, Geo g,
+                                                               double *ws) {
+  const int grp = threadIdx.x >> 4, role = threadIdx.x & 15;
+  const long p = (long)blockIdx.x * WIDE_NLP_PER_BLOCK + grp;
+  const unsigned L = (unsigned)(p & (WAVE - 1));
+  const QTile t_((gdbl *)ws + (size_t)(blockIdx.x >> 2) * g.tile_doubles(), L);
+  gdbl *sc = scal_base(t_, g);
+  if (p >= batch || (int)SC(X_STATE) != ST_FACTORED) return;
+  const Der d = derive(params[p]);
+  const int K = g.K;
+  const unsigned oc = L + (unsigned)((int)SC(X_CUR)) * (21 * WAVE);
+  const Scal s = load_scal(t_, sc, X_S);
+  const double mu = SC(X_MU), dth = SC(X_DTH), dnu3 = SC(X_DNU3);
+  const double sig1 = SC(X_SIG1), sig2 = SC(X_SIG2), rs1 = SC(X_RS1), rs2 = SC(X_RS2);
+  const double hT = (1.0 / K) * d.T, dt = hT * s.th, cs = dt;
+  const double tau = fmax(0.99, 1.0 - mu);
+  const int rowA = role < 8 ? Q_G + role : role < 12 ? Q_E + role - 8 : Q_G;
+  const int rowB = role < 7 ? Q_R + role : role < 14 ? Q_C + role - 7 : Q_R;
+  const unsigned offA = (unsigned)rowA * WAVE + L, offB = (unsigned)rowB * WAVE + L;
+  const unsigned offS = (unsigned)(Q_ST + O_L + (role < 7 ? role : 0)) * WAVE + L;
+  const OneHot<7> hot(role);
+  double dln[7];
+  ASC_UNROLL
+  for (int i = 0; i < 7; i++) dln[i] = 0.0;
+  double cl = 0.0;
+  auto loadV = [&](int k, InV &in) __attribute__((always_inline)) {
+#ifdef WIDE_FAKE
+    const gdbl *sp = t_.st(k & 3);
+#else
+    const gdbl *sp = t_.st(k);
+#endif
+    in.gA = sp[offA]; in.gB = sp[offB];
+  };
+  auto body = [&](InV &in, int k) __attribute__((always_inline)) {
+    gdbl *sp = t_.st(k);
+    const double G[8] = {bcast16<0>(in.gA), bcast16<1>(in.gA), bcast16<2>(in.gA), bcast16<3>(in.gA),
+                         bcast16<4>(in.gA), bcast16<5>(in.gA), bcast16<6>(in.gA), bcast16<7>(in.gA)};
+    const double E[4] = {bcast16<8>(in.gA), bcast16<9>(in.gA), bcast16<10>(in.gA), bcast16<11>(in.gA)};
+    const double rr[7] = {bcast16<0>(in.gB), bcast16<1>(in.gB), bcast16<2>(in.gB), bcast16<3>(in.gB),
+                          bcast16<4>(in.gB), bcast16<5>(in.gB), bcast16<6>(in.gB)};
+    const double cc[7] = {bcast16<7>(in.gB), bcast16<8>(in.gB), bcast16<9>(in.gB), bcast16<10>(in.gB),
+                          bcast16<11>(in.gB), bcast16<12>(in.gB), bcast16<13>(in.gB)};
+    double r[7], dl[7];
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) r[i] = (FORM == 1 && i == IA) ? rr[i] : rr[i] + dln[i];
+    solveAT<FORM>(G, E, cs, r, dl);
+    if (role < 7) sp[offS] = hot.pick(dl);
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) cl += cc[i] * dl[i];
+    cpy<7>(dln, dl);
+  };
+#define LD_(k_, buf_) loadV(k_, buf_)
+  ASC_SWEEP_BACKWARD4(InV, LD_, body)
+#undef LD_
+  if (role != 0) return;
+  double rmax = 0.0, gsum = 0.0, adu = 1.0;
+  for (int c = 0; c < g.nch; c++) {
+    const gdbl *pp = part_base(t_, g, c);
+    rmax = fmax(rmax, ROW(pp, 0)); gsum += ROW(pp, 1); adu = fmin(adu, ROW(pp, 2)); cl += ROW(pp, 3);
+  }
+  double zK[7], dzK[7];
+  ldo<7>(t_.st(K - 1), Q_IT + O_Z, oc, zK);
+  ldn<7>(t_, t_.st(K - 1), Q_ST + O_Z, dzK);
+  const Terminal tm = terminal_eval(d, zK);
+  Scal ds;
+  ds.th = dth; ds.nu3 = dnu3;
+  ds.s1 = (tm.g1 - s.s1) + tm.g1g[0] * dzK[IX] + tm.g1g[1] * dzK[IY];
+  ds.s2 = (tm.g2 - s.s2) + tm.g2g[0] * dzK[IVX] + tm.g2g[1] * dzK[IVY];
+  ds.nu1 = sig1 * ds.s1 + rs1;
+  ds.nu2 = sig2 * ds.s2 + rs2;
+  ds.zs1 = mu / s.s1 - s.zs1 - s.zs1 / s.s1 * ds.s1;
+  ds.zs2 = mu / s.s2 - s.zs2 - s.zs2 / s.s2 * ds.s2;
+  const double dl_ = s.th - d.tlb, dU = d.tub - s.th;
+  ds.zlt = mu / dl_ - s.zlt - s.zlt / dl_ * ds.th;
+  ds.zut = mu / dU - s.zut + s.zut / dU * ds.th;
+  double apr = 1.0;
+  if (rmax * apr > tau) apr = tau / rmax;
+  ASC_FTB(apr, dl_, ds.th); ASC_FTB(apr, dU, -ds.th);
+  ASC_FTB(apr, s.s1, ds.s1); ASC_FTB(apr, s.s2, ds.s2);
+  ASC_FTB(adu, s.zlt, ds.zlt); ASC_FTB(adu, s.zut, ds.zut);
+  ASC_FTB(adu, s.zs1, ds.zs1); ASC_FTB(adu, s.zs2, ds.zs2);
+  double gd = mu * gsum;
+  gd += ds.th * (1.0 - mu / dl_ + mu / dU) - mu * ds.s1 / s.s1 - mu * ds.s2 / s.s2;
+  cl += tm.e3 * (s.nu3 + ds.nu3) + (tm.g1 - s.s1) * (s.nu1 + ds.nu1) + (tm.g2 - s.s2) * (s.nu2 + ds.nu2);
+  const double c1 = SC(X_C1), slog = SC(X_SL);
+  double nu_pen = SC(X_NUP);
+  const double curv = -gd + cl;
+  if (c1 > 0.0) {
+    const double need = (gd + 0.5 * fmax(curv, 0.0)) / (0.9 * c1);
+    if (nu_pen < need) nu_pen = need + 1.0;
+  }
+  store_scal(t_, sc, X_D, ds);
+  SC(X_NUP) = nu_pen;
+  SC(X_DM) = gd - nu_pen * c1;
+  SC(X_PHI0) = s.th - mu * slog + nu_pen * c1;
+  SC(X_ALPHA) = apr; SC(X_ADU) = adu; SC(X_LS) = 0.0;
+  SC(X_STATE) = ST_TRIAL;
+}
+
+// ==============================================================================================
 // q_finish: results from each lane's current iterate buffer
 // ==============================================================================================
 __global__ __launch_bounds__(WAVE) void q_finish(const ascent_params *params, long batch, Geo g, double *ws,
@@ -1039,6 +1471,9 @@ int pipeline_run(const ascent_params *dp, long batch, int K, int scheme, int for
   // `burst` rounds back to back and reads the counters of the last one only then -- the device never waits
   // for the host inside a burst.  A lane needs at most max_iter+1 accepted trial points plus a bounded number
   // of rejected trials and refactorisations per iteration, so the loop terminates.
+  // the 16-lanes-per-NLP factorisation pays while the chip has idle SIMDs (see q_factor_wide)
+  bool wide = scheme == 0 && batch <= 8192;
+  if (const char *e = getenv("ASCENT_FACTOR")) wide = scheme == 0 && e[0] == 'w';
   int burst = 4;
   if (const char *e = getenv("ASCENT_ROUNDS_PER_SYNC")) { const int v = atoi(e); if (v >= 1 && v <= 64) burst = v; }
 #define ASC_LAUNCH(KERNEL, GRID, ...)                                                                               \
@@ -1052,11 +1487,21 @@ int pipeline_run(const ascent_params *dp, long batch, int K, int scheme, int for
     for (int r = 0; r < burst; r++, round++) {
       ASC_LAUNCH(q_trial_eval, dim3(tiles, g.nch), dp, batch, g, ws);
       PCHK(hipMemsetAsync(counters, 0, 3 * sizeof(int), stream));
-      ASC_LAUNCH(q_decide_factor, dim3(tiles), dp, batch, g, ws, max_iter, tol, counters);
+      ASC_LAUNCH(q_decide_factor, dim3(tiles), dp, batch, g, ws, max_iter, tol, counters, wide ? 0 : 1);
+      if (wide) {
+        const dim3 wgrid((unsigned)((batch + WIDE_NLP_PER_BLOCK - 1) / WIDE_NLP_PER_BLOCK));
+        if (form == 1) hipLaunchKernelGGL((q_factor_wide<1>), wgrid, dim3(WIDE_THREADS), 0, stream, dp, batch, g, ws, counters);
+        else hipLaunchKernelGGL((q_factor_wide<0>), wgrid, dim3(WIDE_THREADS), 0, stream, dp, batch, g, ws, counters);
+      }
       if (r == burst - 1) PCHK(hipMemcpyAsync(host_cnt, counters, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
-      ASC_LAUNCH(q_forward, dim3(tiles), dp, batch, g, ws);
+      const dim3 wgrid((unsigned)((batch + WIDE_NLP_PER_BLOCK - 1) / WIDE_NLP_PER_BLOCK));
+      if (!wide) ASC_LAUNCH(q_forward, dim3(tiles), dp, batch, g, ws);
+      else if (form == 1) hipLaunchKernelGGL((q_forward_wide<1>), wgrid, dim3(WIDE_THREADS), 0, stream, dp, batch, g, ws);
+      else hipLaunchKernelGGL((q_forward_wide<0>), wgrid, dim3(WIDE_THREADS), 0, stream, dp, batch, g, ws);
       hipLaunchKernelGGL(q_local, dim3(tiles, g.nch), dim3(WAVE), 0, stream, dp, batch, g, ws);
-      ASC_LAUNCH(q_adjoint, dim3(tiles), dp, batch, g, ws);
+      if (!wide) ASC_LAUNCH(q_adjoint, dim3(tiles), dp, batch, g, ws);
+      else if (form == 1) hipLaunchKernelGGL((q_adjoint_wide<1>), wgrid, dim3(WIDE_THREADS), 0, stream, dp, batch, g, ws);
+      else hipLaunchKernelGGL((q_adjoint_wide<0>), wgrid, dim3(WIDE_THREADS), 0, stream, dp, batch, g, ws);
       launches += 5;
     }
     PCHK(hipStreamSynchronize(stream));
