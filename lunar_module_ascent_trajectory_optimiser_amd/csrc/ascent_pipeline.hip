@@ -776,12 +776,9 @@ __global__ __launch_bounds__(WIDE_THREADS) void q_factor_wide(const ascent_param
                    : role == 14 ? Q_SC + 4 : Q_SC + 2;
   const int rowB = role < 7 ? Q_C + role : role < 14 ? Q_F + role - 7 : role == 14 ? Q_SC + 3 : Q_SC;
   const unsigned offA = (unsigned)rowA * WAVE + L, offB = (unsigned)rowB * WAVE + L;
+  const unsigned offK = (unsigned)(role < 7 ? Q_KA + role : role < 10 ? Q_K0 + role - 7 : Q_R + role - 10) * WAVE + L;
   auto loadW = [&](int k, InW &in) __attribute__((always_inline)) {
-#ifdef WIDE_FAKE
-    const gdbl *sp = t_.st(k & 3);
-#else
     const gdbl *sp = t_.st(k);
-#endif
     ASC_UNROLL
     for (int i = 0; i < 7; i++) in.gq[i] = sp[goff[i]];
     in.gA = sp[offA];
@@ -871,7 +868,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void q_factor_wide(const ascent_param
     const double coef = (bu * b[IB] - rsel) * iD;        // kap_c on column lanes, k0_j on lanes 7-9
     ASC_UNROLL
     for (int i = 0; i < 7; i++) a[i] = b[i] - mw[i] * coef;   // P column / q_j
-    if (role < 10) sp[(unsigned)(role < 7 ? Q_KA + role : Q_K0 + role - 7) * WAVE + L] = coef;
+    sp[offK] = coef;      // lanes 10-15 write into rows of Q_R, which q_local rewrites before anything reads them
     // P rc_0, P rc_1 (rc_0 = -c, rc_1 = hT F, rc_2 = 0): by symmetry element c is the dot product with column c
     if (col) {
       double d0 = 0.0, d1 = 0.0;
@@ -901,7 +898,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void q_factor_wide(const ascent_param
     k10 += Dk1 * k00; k11 += Dk1 * k01; k12 += Dk1 * k02; k20 += Dk2 * k00; k22 += Dk2 * k02;
   };
 #define LD_(k_, buf_) loadW(k_, buf_)
-  ASC_SWEEP_BACKWARD4(InW, LD_, body)
+  ASC_SWEEP_BACKWARD4U(InW, LD_, body)
 #undef LD_
   const double U0 = bcast16<7>(U), U1 = bcast16<8>(U), V1 = bcast16<8>(V), U2 = bcast16<9>(U), V2 = bcast16<9>(V);
   if (role != 0) return;
@@ -1205,7 +1202,7 @@ struct OneHot {
   double m[N];
   ASC_DEV explicit OneHot(int role) {
     ASC_UNROLL
-    for (int i = 0; i < N; i++) m[i] = role == i ? 1.0 : 0.0;
+    for (int i = 0; i < N; i++) m[i] = (role == i || (i == 0 && role >= N)) ? 1.0 : 0.0;
   }
   ASC_DEV double pick(const double *v) const {
     double r = m[0] * v[0];
@@ -1232,17 +1229,15 @@ __global__ __launch_bounds__(WIDE_THREADS) void q_forward_wide(const ascent_para
   const int rowB = role < 7 ? Q_C + role : role < 14 ? Q_F + role - 7 : Q_C;
   const int rowC = role < 7 ? Q_KA + role : Q_KA;
   const unsigned offA = (unsigned)rowA * WAVE + L, offB = (unsigned)rowB * WAVE + L, offC = (unsigned)rowC * WAVE + L;
-  const unsigned offS = (unsigned)(Q_ST + (role < 8 ? role : 0)) * WAVE + L;     // dz[0..6], du are rows Q_ST + 0..7
+  // dz[0..6], du are rows Q_ST + 0..7; lanes 8-15 store what lane 0 stores (an unconditional store keeps the
+  // compiler's s_waitcnt bookkeeping exact)
+  const unsigned offS = (unsigned)(Q_ST + (role < 8 ? role : 0)) * WAVE + L;
   const OneHot<8> hot(role);
   double dzp[7];
   ASC_UNROLL
   for (int i = 0; i < 7; i++) dzp[i] = 0.0;
   auto loadV = [&](int k, InV &in) __attribute__((always_inline)) {
-#ifdef WIDE_FAKE
-    const gdbl *sp = t_.st(k & 3);
-#else
     const gdbl *sp = t_.st(k);
-#endif
     in.gA = sp[offA]; in.gB = sp[offB]; in.gC = sp[offC];
   };
   auto body = [&](InV &in, int k) __attribute__((always_inline)) {
@@ -1257,9 +1252,10 @@ __global__ __launch_bounds__(WIDE_THREADS) void q_forward_wide(const ascent_para
                          bcast16<11>(in.gB), bcast16<12>(in.gB), bcast16<13>(in.gB)};
     const double ka[7] = {bcast16<0>(in.gC), bcast16<1>(in.gC), bcast16<2>(in.gC), bcast16<3>(in.gC),
                           bcast16<4>(in.gC), bcast16<5>(in.gC), bcast16<6>(in.gC)};
+    __builtin_amdgcn_sched_barrier(0);   // all broadcasts first: a DPP result consumed at once stalls the wavefront
     double xi[7], dz[8];
-    double du = k0[0] + k0[1] * dth + k0[2] * dnu3;
     if (FORM == 1) dzp[IA] = 0.0;     // the angle row has no coupling to the previous angle
+    double du = k0[0] + k0[1] * dth + k0[2] * dnu3;
     ASC_UNROLL
     for (int i = 0; i < 7; i++) {
       xi[i] = dzp[i] - cc[i] + hT * F[i] * dth;
@@ -1268,11 +1264,11 @@ __global__ __launch_bounds__(WIDE_THREADS) void q_forward_wide(const ascent_para
     if (FORM == 1) xi[IA] += 0.5 * d.aub * du; else xi[IW] += be * du;
     solveA<FORM>(G, E, cs, xi, dz);
     dz[7] = du;
-    if (role < 8) sp[offS] = hot.pick(dz);
+    sp[offS] = hot.pick(dz);
     cpy<7>(dzp, dz);
   };
 #define LD_(k_, buf_) loadV(k_, buf_)
-  ASC_SWEEP_FORWARD4(InV, LD_, body)
+  ASC_SWEEP_FORWARD8U(InV, LD_, body)
 #undef LD_
 }
 
@@ -1303,11 +1299,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void q_adjoint_wide(const ascent_para
   for (int i = 0; i < 7; i++) dln[i] = 0.0;
   double cl = 0.0;
   auto loadV = [&](int k, InV &in) __attribute__((always_inline)) {
-#ifdef WIDE_FAKE
-    const gdbl *sp = t_.st(k & 3);
-#else
     const gdbl *sp = t_.st(k);
-#endif
     in.gA = sp[offA]; in.gB = sp[offB];
   };
   auto body = [&](InV &in, int k) __attribute__((always_inline)) {
@@ -1319,17 +1311,18 @@ __global__ __launch_bounds__(WIDE_THREADS) void q_adjoint_wide(const ascent_para
                           bcast16<4>(in.gB), bcast16<5>(in.gB), bcast16<6>(in.gB)};
     const double cc[7] = {bcast16<7>(in.gB), bcast16<8>(in.gB), bcast16<9>(in.gB), bcast16<10>(in.gB),
                           bcast16<11>(in.gB), bcast16<12>(in.gB), bcast16<13>(in.gB)};
+    __builtin_amdgcn_sched_barrier(0);   // all broadcasts first (see q_forward_wide)
     double r[7], dl[7];
     ASC_UNROLL
     for (int i = 0; i < 7; i++) r[i] = (FORM == 1 && i == IA) ? rr[i] : rr[i] + dln[i];
     solveAT<FORM>(G, E, cs, r, dl);
-    if (role < 7) sp[offS] = hot.pick(dl);
+    sp[offS] = hot.pick(dl);
     ASC_UNROLL
     for (int i = 0; i < 7; i++) cl += cc[i] * dl[i];
     cpy<7>(dln, dl);
   };
 #define LD_(k_, buf_) loadV(k_, buf_)
-  ASC_SWEEP_BACKWARD4(InV, LD_, body)
+  ASC_SWEEP_BACKWARD8U(InV, LD_, body)
 #undef LD_
   if (role != 0) return;
   double rmax = 0.0, gsum = 0.0, adu = 1.0;

@@ -140,6 +140,131 @@ ASC_DEV double clipz(double zv, double dist, double mu) {
     if (k + 2 < K) BODY(b2_, k + 2);                       \
   }
 
+// The four-buffer skeletons with unconditional prefetches (the step index is clamped at the end of the sweep
+// instead of guarding the load): a load under a branch makes the compiler's s_waitcnt placement assume the
+// shorter queue and wait for the newest loads.  Used by the 16-lanes-per-NLP sweeps, whose steps are short; the
+// one-lane-per-NLP passes measured slower with it (more live registers across the body) and keep the guards.
+#define ASC_CLAMP_LO_(k_) ((k_) > 0 ? (k_) : 0)
+#define ASC_CLAMP_HI_(k_) ((k_) < K - 1 ? (k_) : K - 1)
+// the fence keeps the prefetches where they are written: one full body ahead of each use
+#define ASC_SCHED_FENCE_ __builtin_amdgcn_sched_barrier(0)
+#define ASC_SWEEP_BACKWARD4U(IN, LOAD, BODY)             \
+  {                                                      \
+    IN b0_, b1_, b2_, b3_;                               \
+    int k = K - 1;                                       \
+    LOAD(ASC_CLAMP_LO_(k - 0), b0_); ASC_SCHED_FENCE_;   \
+    LOAD(ASC_CLAMP_LO_(k - 1), b1_); ASC_SCHED_FENCE_;   \
+    LOAD(ASC_CLAMP_LO_(k - 2), b2_); ASC_SCHED_FENCE_;   \
+    for (; k >= 3; k -= 4) {                             \
+      LOAD(ASC_CLAMP_LO_(k - 3), b3_); ASC_SCHED_FENCE_; \
+      BODY(b0_, k - 0);                                  \
+      LOAD(ASC_CLAMP_LO_(k - 4), b0_); ASC_SCHED_FENCE_; \
+      BODY(b1_, k - 1);                                  \
+      LOAD(ASC_CLAMP_LO_(k - 5), b1_); ASC_SCHED_FENCE_; \
+      BODY(b2_, k - 2);                                  \
+      LOAD(ASC_CLAMP_LO_(k - 6), b2_); ASC_SCHED_FENCE_; \
+      BODY(b3_, k - 3);                                  \
+    }                                                    \
+    if (k >= 0) BODY(b0_, k - 0);                        \
+    if (k >= 1) BODY(b1_, k - 1);                        \
+    if (k >= 2) BODY(b2_, k - 2);                        \
+  }
+#define ASC_SWEEP_FORWARD4U(IN, LOAD, BODY)              \
+  {                                                      \
+    IN b0_, b1_, b2_, b3_;                               \
+    int k = 0;                                           \
+    LOAD(ASC_CLAMP_HI_(0), b0_); ASC_SCHED_FENCE_;       \
+    LOAD(ASC_CLAMP_HI_(1), b1_); ASC_SCHED_FENCE_;       \
+    LOAD(ASC_CLAMP_HI_(2), b2_); ASC_SCHED_FENCE_;       \
+    for (; k + 3 < K; k += 4) {                          \
+      LOAD(ASC_CLAMP_HI_(k + 3), b3_); ASC_SCHED_FENCE_; \
+      BODY(b0_, k + 0);                                  \
+      LOAD(ASC_CLAMP_HI_(k + 4), b0_); ASC_SCHED_FENCE_; \
+      BODY(b1_, k + 1);                                  \
+      LOAD(ASC_CLAMP_HI_(k + 5), b1_); ASC_SCHED_FENCE_; \
+      BODY(b2_, k + 2);                                  \
+      LOAD(ASC_CLAMP_HI_(k + 6), b2_); ASC_SCHED_FENCE_; \
+      BODY(b3_, k + 3);                                  \
+    }                                                    \
+    if (k + 0 < K) BODY(b0_, k + 0);                     \
+    if (k + 1 < K) BODY(b1_, k + 1);                     \
+    if (k + 2 < K) BODY(b2_, k + 2);                     \
+  }
+#define ASC_SWEEP_BACKWARD8U(IN, LOAD, BODY)              \
+  {                                                       \
+    IN b0_, b1_, b2_, b3_, b4_, b5_, b6_, b7_;            \
+    int k = K - 1;                                        \
+    LOAD(ASC_CLAMP_LO_(k - 0), b0_); ASC_SCHED_FENCE_;    \
+    LOAD(ASC_CLAMP_LO_(k - 1), b1_); ASC_SCHED_FENCE_;    \
+    LOAD(ASC_CLAMP_LO_(k - 2), b2_); ASC_SCHED_FENCE_;    \
+    LOAD(ASC_CLAMP_LO_(k - 3), b3_); ASC_SCHED_FENCE_;    \
+    LOAD(ASC_CLAMP_LO_(k - 4), b4_); ASC_SCHED_FENCE_;    \
+    LOAD(ASC_CLAMP_LO_(k - 5), b5_); ASC_SCHED_FENCE_;    \
+    LOAD(ASC_CLAMP_LO_(k - 6), b6_); ASC_SCHED_FENCE_;    \
+    for (; k >= 7; k -= 8) {                              \
+      LOAD(ASC_CLAMP_LO_(k - 7), b7_); ASC_SCHED_FENCE_;  \
+      BODY(b0_, k - 0);                                   \
+      LOAD(ASC_CLAMP_LO_(k - 8), b0_); ASC_SCHED_FENCE_;  \
+      BODY(b1_, k - 1);                                   \
+      LOAD(ASC_CLAMP_LO_(k - 9), b1_); ASC_SCHED_FENCE_;  \
+      BODY(b2_, k - 2);                                   \
+      LOAD(ASC_CLAMP_LO_(k - 10), b2_); ASC_SCHED_FENCE_; \
+      BODY(b3_, k - 3);                                   \
+      LOAD(ASC_CLAMP_LO_(k - 11), b3_); ASC_SCHED_FENCE_; \
+      BODY(b4_, k - 4);                                   \
+      LOAD(ASC_CLAMP_LO_(k - 12), b4_); ASC_SCHED_FENCE_; \
+      BODY(b5_, k - 5);                                   \
+      LOAD(ASC_CLAMP_LO_(k - 13), b5_); ASC_SCHED_FENCE_; \
+      BODY(b6_, k - 6);                                   \
+      LOAD(ASC_CLAMP_LO_(k - 14), b6_); ASC_SCHED_FENCE_; \
+      BODY(b7_, k - 7);                                   \
+    }                                                     \
+    if (k >= 0) BODY(b0_, k - 0);                         \
+    if (k >= 1) BODY(b1_, k - 1);                         \
+    if (k >= 2) BODY(b2_, k - 2);                         \
+    if (k >= 3) BODY(b3_, k - 3);                         \
+    if (k >= 4) BODY(b4_, k - 4);                         \
+    if (k >= 5) BODY(b5_, k - 5);                         \
+    if (k >= 6) BODY(b6_, k - 6);                         \
+  }
+#define ASC_SWEEP_FORWARD8U(IN, LOAD, BODY)               \
+  {                                                       \
+    IN b0_, b1_, b2_, b3_, b4_, b5_, b6_, b7_;            \
+    int k = 0;                                            \
+    LOAD(ASC_CLAMP_HI_(0), b0_); ASC_SCHED_FENCE_;        \
+    LOAD(ASC_CLAMP_HI_(1), b1_); ASC_SCHED_FENCE_;        \
+    LOAD(ASC_CLAMP_HI_(2), b2_); ASC_SCHED_FENCE_;        \
+    LOAD(ASC_CLAMP_HI_(3), b3_); ASC_SCHED_FENCE_;        \
+    LOAD(ASC_CLAMP_HI_(4), b4_); ASC_SCHED_FENCE_;        \
+    LOAD(ASC_CLAMP_HI_(5), b5_); ASC_SCHED_FENCE_;        \
+    LOAD(ASC_CLAMP_HI_(6), b6_); ASC_SCHED_FENCE_;        \
+    for (; k + 7 < K; k += 8) {                           \
+      LOAD(ASC_CLAMP_HI_(k + 7), b7_); ASC_SCHED_FENCE_;  \
+      BODY(b0_, k + 0);                                   \
+      LOAD(ASC_CLAMP_HI_(k + 8), b0_); ASC_SCHED_FENCE_;  \
+      BODY(b1_, k + 1);                                   \
+      LOAD(ASC_CLAMP_HI_(k + 9), b1_); ASC_SCHED_FENCE_;  \
+      BODY(b2_, k + 2);                                   \
+      LOAD(ASC_CLAMP_HI_(k + 10), b2_); ASC_SCHED_FENCE_; \
+      BODY(b3_, k + 3);                                   \
+      LOAD(ASC_CLAMP_HI_(k + 11), b3_); ASC_SCHED_FENCE_; \
+      BODY(b4_, k + 4);                                   \
+      LOAD(ASC_CLAMP_HI_(k + 12), b4_); ASC_SCHED_FENCE_; \
+      BODY(b5_, k + 5);                                   \
+      LOAD(ASC_CLAMP_HI_(k + 13), b5_); ASC_SCHED_FENCE_; \
+      BODY(b6_, k + 6);                                   \
+      LOAD(ASC_CLAMP_HI_(k + 14), b6_); ASC_SCHED_FENCE_; \
+      BODY(b7_, k + 7);                                   \
+    }                                                     \
+    if (k + 0 < K) BODY(b0_, k + 0);                      \
+    if (k + 1 < K) BODY(b1_, k + 1);                      \
+    if (k + 2 < K) BODY(b2_, k + 2);                      \
+    if (k + 3 < K) BODY(b3_, k + 3);                      \
+    if (k + 4 < K) BODY(b4_, k + 4);                      \
+    if (k + 5 < K) BODY(b5_, k + 5);                      \
+    if (k + 6 < K) BODY(b6_, k + 6);                      \
+  }
+
 #define ASC_FTB(a, val, dv) do { const double dv_ = (dv); if (dv_ < 0.0) a = fmin(a, -tau * (val) / dv_); } while (0)
 // same test with the reciprocal of the distance at hand: alpha <= tau / (-dv/val)
 #define ASC_FTBR(amax_inv, ival, dv) amax_inv = fmax(amax_inv, -(dv) * (ival))

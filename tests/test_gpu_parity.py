@@ -129,6 +129,34 @@ def test_split_and_fused_paths_agree(coracle, monkeypatch):
         assert np.all(m.status == 1) and np.all(m.iters == 4)
 
 
+def test_wide_and_one_lane_sweeps_agree(coracle, monkeypatch):
+    """The split pipeline has two implementations of its three serial sweeps: one lane per NLP, and 16 lanes per
+    NLP (DPP row broadcasts + LDS transpose; used for batches <= 8192; ASCENT_FACTOR=lane|wide overrides).  Same
+    algorithm, different summation order: identical iteration counts, answers equal to rounding, both equal to
+    the oracle; ragged batch sizes exercise partially filled wavefronts and workgroups of the 16-lane kernels."""
+    for B, form, P in ((70, "current", A.sweep_isp_drymass(10, 7)),
+                       (3, "v1", np.repeat(A.AscentParams(r_peri=53108.4, r_apo=53108.4, mass_scalar=2576.0).as_row()[None], 3, 0))):
+        out = {}
+        for mode in ("lane", "wide"):
+            monkeypatch.setenv("ASCENT_PIPELINE", "split")
+            monkeypatch.setenv("ASCENT_FACTOR", mode)
+            out[mode] = A.solve_batch(P, NT, tol=1e-9, want_blob=True, formulation=form, max_iter=500)
+            assert np.all(out[mode].status == 0)
+        assert np.array_equal(out["lane"].iters, out["wide"].iters)
+        assert np.abs(out["lane"].tf - out["wide"].tf).max() <= 1e-12
+        assert np.abs(out["lane"].blob - out["wide"].blob).max() <= 1e-6 * np.abs(out["lane"].blob).max()
+        ref = coracle.solve_batch(P, NT, 500, 1e-9, formulation=1 if form == "v1" else 0)
+        assert np.array_equal(out["wide"].iters, ref["iters"])
+        assert np.abs(out["wide"].tf - ref["tf"]).max() <= 1e-9 * ref["tf"].max()
+    # the inertia-correction path of the 16-lane factorisation (needs a regularised step somewhere in the sweep)
+    S = A.sweep_isp_drymass()[::37]
+    monkeypatch.setenv("ASCENT_FACTOR", "wide")
+    w = A.solve_batch(S, NT, tol=1e-9)
+    monkeypatch.setenv("ASCENT_FACTOR", "lane")
+    l = A.solve_batch(S, NT, tol=1e-9)
+    assert np.all(w.status == 0) and np.array_equal(w.iters, l.iters) and np.abs(w.tf - l.tf).max() <= 1e-12
+
+
 def test_ragged_batch_and_small_grids(coracle):
     """Batch sizes that are not multiples of the wave size, and other grid sizes."""
     for B, nt in ((1, 3), (3, 12), (65, 50), (130, 25)):
