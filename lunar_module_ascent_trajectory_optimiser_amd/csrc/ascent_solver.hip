@@ -716,7 +716,7 @@ __global__ __launch_bounds__(WAVE) void k_solve(const ascent_params *params, lon
     StepInfo si;
     bool fail = false;
     while (newton_step(w, s, mu, dw, ds, si)) {
-      dw = dw == 0.0 ? fmax(1e-4, dw_last / 3.0) : dw * 8.0;
+      dw = next_delta_w(dw, dw_last);
       if (dw > 1e10) { fail = true; break; }
     }
     if (fail) { status = ASCENT_REGULARISATION_FAILED; break; }

@@ -538,7 +538,8 @@ static int solve_one(const oparams *prm, int nt, int max_iter, double tol, int u
     for (;;) {
       assemble(&d, w, &it, mu, dw);
       if (kkt_solve(&d, w, &it, mu) == 0) break;
-      dw = dw == 0.0 ? fmax(1e-4, dw_last / 3.0) : dw * 8.0;
+      /* inertia correction: first one of a solve 1e-2, later ones a third of the last successful value, x10 while wrong */
+      dw = dw == 0.0 ? (dw_last == 0.0 ? 1e-2 : fmax(1e-4, dw_last / 3.0)) : dw * 10.0;
       nreg++;
       if (dw > 1e10) { fail = 1; break; }
     }
