@@ -199,14 +199,15 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": ("split pipeline: q_trial_eval + q_decide_factor (dominant) + q_forward + q_local + q_adjoint, one set per interior-point round"
-                           if B <= 12288 else "k_solve (fused)"),
+                "kernel": ("split pipeline, 16-lane sweeps: q_trial_eval + q_decide_factor + q_factor_wide (dominant) + q_forward_wide + q_local + "
+                           "q_adjoint_wide, one set per interior-point round" if B <= 8192 else
+                           "split pipeline, one-lane sweeps" if B <= 12288 else "k_solve (fused)"),
                 "kernel_ms": k_ms, "algorithmic_bytes_per_launch": b_alg,
                 "fp64_achieved_tflops": f_alg / (k_ms * 1e-3) / 1e12,
                 "fp64_frac": f_alg / (k_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
                 "note": ("kernel_ms = device time of one whole solve (HIP events around all launches of the step); achieved = SURVEY 8d "
                          "algorithmic bytes of the solve / that time. The node-parallel kernels run at HBM rate; the three serial sweeps are "
-                         "FP64-issue/latency bound: see DESIGN.md section 5"),
+                         "FP64-issue bound (one wavefront per SIMD): see DESIGN.md section 5"),
             },
         }
         if world == 1 and not args.no_continuation:

@@ -776,7 +776,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void q_factor_wide(const ascent_param
                    : role == 14 ? Q_SC + 4 : Q_SC + 2;
   const int rowB = role < 7 ? Q_C + role : role < 14 ? Q_F + role - 7 : role == 14 ? Q_SC + 3 : Q_SC;
   const unsigned offA = (unsigned)rowA * WAVE + L, offB = (unsigned)rowB * WAVE + L;
-  const unsigned offK = (unsigned)(role < 7 ? Q_KA + role : role < 10 ? Q_K0 + role - 7 : Q_R + role - 10) * WAVE + L;
+  const unsigned offK = (unsigned)(role < 7 ? Q_KA + role : role < 10 ? Q_K0 + role - 7 : Q_R) * WAVE + L;
   auto loadW = [&](int k, InW &in) __attribute__((always_inline)) {
     const gdbl *sp = t_.st(k);
     ASC_UNROLL
@@ -868,7 +868,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void q_factor_wide(const ascent_param
     const double coef = (bu * b[IB] - rsel) * iD;        // kap_c on column lanes, k0_j on lanes 7-9
     ASC_UNROLL
     for (int i = 0; i < 7; i++) a[i] = b[i] - mw[i] * coef;   // P column / q_j
-    sp[offK] = coef;      // lanes 10-15 write into rows of Q_R, which q_local rewrites before anything reads them
+    sp[offK] = coef;      // lanes 10-15 all write into the first row of Q_R, which q_local rewrites before anything reads it
     // P rc_0, P rc_1 (rc_0 = -c, rc_1 = hT F, rc_2 = 0): by symmetry element c is the dot product with column c
     if (col) {
       double d0 = 0.0, d1 = 0.0;
