@@ -713,7 +713,7 @@ __global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *par
 // between; the pivot column is handed round with DPP row broadcasts; P*rc comes from column dot products (P is
 // symmetric) moved to the right-hand-side lanes through LDS.  One wavefront = 4 NLPs, one workgroup = 4
 // wavefronts = 16 NLPs (a quarter tile: every 512-byte workspace row is read as four 128-byte pieces).
-// ~4x fewer instructions per step on the critical path, 16x more wavefronts.  Backward Euler only.
+// ~4x fewer instructions per step on the critical path, 16x more wavefronts.
 constexpr int WIDE_NLP_PER_BLOCK = 16, WIDE_THREADS = 256;
 
 template <int SRC>
@@ -730,7 +730,7 @@ struct InW {
   double gq[7], gA, gB;
 };
 
-template <int FORM>
+template <int SCHEME, int FORM>
 __global__ __launch_bounds__(WIDE_THREADS) void q_factor_wide(const ascent_params *params, long batch, Geo g,
                                                               double *ws, int *counters) {
   __shared__ double lds_t[WIDE_THREADS / 16][7][7];     // [group][column][row]
@@ -748,7 +748,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void q_factor_wide(const ascent_param
   const Scal s = load_scal(t_, sc, X_S);
   const double dw = SC(X_DW);
   const double hT = (1.0 / K) * d.T, dt = hT * s.th, be = dt * d.alpha, ith = rcp(s.th);
-  const double cs = dt;
+  const double cs = SCHEME == 1 ? 0.5 * dt : dt;
   constexpr int IB = FORM == 1 ? IA : IW;
   const double bu = FORM == 1 ? 0.5 * d.aub : be;
   const bool col = role < 7, rhs = role >= 7 && role < 10;
@@ -834,6 +834,29 @@ __global__ __launch_bounds__(WIDE_THREADS) void q_factor_wide(const ascent_param
     const double rc1[7] = {hT * bcast16<7>(in.gB), hT * bcast16<8>(in.gB), hT * bcast16<9>(in.gB),
                            hT * bcast16<10>(in.gB), hT * bcast16<11>(in.gB), hT * bcast16<12>(in.gB),
                            hT * bcast16<13>(in.gB)};
+    if (SCHEME == 1 && k < K - 1) {   // pull the value function of step k+1 back through Abar = I + cs*F_z(z_k):
+      double t[7];                    // Abar' on every column and right-hand side, transpose, Abar' on the columns again
+      fzt_lambda(G, a, t);
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) a[i] += cs * t[i];
+      if (col) {
+        ASC_UNROLL
+        for (int i = 0; i < 7; i++) lds_t[grp][role][i] = a[i];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      if (col) {
+        double r[7];
+        ASC_UNROLL
+        for (int l = 0; l < 7; l++) r[l] = lds_t[grp][l][role];
+        fzt_lambda(G, r, t);
+        ASC_UNROLL
+        for (int i = 0; i < 7; i++) a[i] = r[i] + cs * t[i];
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // lds_t is written again below
+      __builtin_amdgcn_wave_barrier();
+    }
     ASC_UNROLL
     for (int i = 0; i < 7; i++) a[i] += gsc[i] * in.gq[i];
     a[IA] += bsc * bza;
@@ -1191,7 +1214,7 @@ __global__ __launch_bounds__(WAVE) void q_adjoint(const ascent_params *params, l
 // The substitutions are short vector recurrences whose cost is fetching ~30 rows per step: with one lane per NLP
 // that is ~30 load instructions per step and a wavefront cannot keep more than 64 in flight.  Here the 16 lanes
 // of an NLP fetch 16 different rows with one gather, hand them round with row broadcasts and all compute the
-// (tiny) step redundantly; lane i stores element i.  Backward Euler only.
+// (tiny) step redundantly; lane i stores element i.
 struct InV {
   double gA, gB, gC;
 };
@@ -1212,7 +1235,7 @@ struct OneHot {
   }
 };
 
-template <int FORM>
+template <int SCHEME, int FORM>
 __global__ __launch_bounds__(WIDE_THREADS) void q_forward_wide(const ascent_params *params, long batch, Geo g,
                                                                double *ws) {
   const int grp = threadIdx.x >> 4, role = threadIdx.x & 15;
@@ -1224,7 +1247,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void q_forward_wide(const ascent_para
   const Der d = derive(params[p]);
   const int K = g.K;
   const double th = SC(X_S + S_TH), dth = SC(X_DTH), dnu3 = SC(X_DNU3);
-  const double hT = (1.0 / K) * d.T, dt = hT * th, be = dt * d.alpha, cs = dt;
+  const double hT = (1.0 / K) * d.T, dt = hT * th, be = dt * d.alpha, cs = SCHEME == 1 ? 0.5 * dt : dt;
   const int rowA = role < 8 ? Q_G + role : role < 12 ? Q_E + role - 8 : role < 15 ? Q_K0 + role - 12 : Q_G;
   const int rowB = role < 7 ? Q_C + role : role < 14 ? Q_F + role - 7 : Q_C;
   const int rowC = role < 7 ? Q_KA + role : Q_KA;
@@ -1233,9 +1256,11 @@ __global__ __launch_bounds__(WIDE_THREADS) void q_forward_wide(const ascent_para
   // compiler's s_waitcnt bookkeeping exact)
   const unsigned offS = (unsigned)(Q_ST + (role < 8 ? role : 0)) * WAVE + L;
   const OneHot<8> hot(role);
-  double dzp[7];
+  double dzp[7], Gp[8];          // previous step's dz; for the trapezoid also its Jacobian block (Abar_k = I + cs*F_z(z_{k-1}))
   ASC_UNROLL
   for (int i = 0; i < 7; i++) dzp[i] = 0.0;
+  ASC_UNROLL
+  for (int i = 0; i < 8; i++) Gp[i] = 0.0;
   auto loadV = [&](int k, InV &in) __attribute__((always_inline)) {
     const gdbl *sp = t_.st(k);
     in.gA = sp[offA]; in.gB = sp[offB]; in.gC = sp[offC];
@@ -1254,6 +1279,12 @@ __global__ __launch_bounds__(WIDE_THREADS) void q_forward_wide(const ascent_para
                           bcast16<4>(in.gC), bcast16<5>(in.gC), bcast16<6>(in.gC)};
     __builtin_amdgcn_sched_barrier(0);   // all broadcasts first: a DPP result consumed at once stalls the wavefront
     double xi[7], dz[8];
+    if (SCHEME == 1) {
+      double t2_[7];
+      fz_mul(Gp, dzp, t2_);
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) dzp[i] += cs * t2_[i];
+    }
     if (FORM == 1) dzp[IA] = 0.0;     // the angle row has no coupling to the previous angle
     double du = k0[0] + k0[1] * dth + k0[2] * dnu3;
     ASC_UNROLL
@@ -1266,13 +1297,14 @@ __global__ __launch_bounds__(WIDE_THREADS) void q_forward_wide(const ascent_para
     dz[7] = du;
     sp[offS] = hot.pick(dz);
     cpy<7>(dzp, dz);
+    if (SCHEME == 1) cpy<8>(Gp, G);
   };
 #define LD_(k_, buf_) loadV(k_, buf_)
   ASC_SWEEP_FORWARD8U(InV, LD_, body)
 #undef LD_
 }
 
-template <int FORM>
+template <int SCHEME, int FORM>
 __global__ __launch_bounds__(WIDE_THREADS) void q_adjoint_wide(const ascent_params *params, long batch, Geo g,
                                                                double *ws) {
   const int grp = threadIdx.x >> 4, role = threadIdx.x & 15;
@@ -1287,7 +1319,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void q_adjoint_wide(const ascent_para
   const Scal s = load_scal(t_, sc, X_S);
   const double mu = SC(X_MU), dth = SC(X_DTH), dnu3 = SC(X_DNU3);
   const double sig1 = SC(X_SIG1), sig2 = SC(X_SIG2), rs1 = SC(X_RS1), rs2 = SC(X_RS2);
-  const double hT = (1.0 / K) * d.T, dt = hT * s.th, cs = dt;
+  const double hT = (1.0 / K) * d.T, dt = hT * s.th, cs = SCHEME == 1 ? 0.5 * dt : dt;
   const double tau = fmax(0.99, 1.0 - mu);
   const int rowA = role < 8 ? Q_G + role : role < 12 ? Q_E + role - 8 : Q_G;
   const int rowB = role < 7 ? Q_R + role : role < 14 ? Q_C + role - 7 : Q_R;
@@ -1315,6 +1347,12 @@ __global__ __launch_bounds__(WIDE_THREADS) void q_adjoint_wide(const ascent_para
     double r[7], dl[7];
     ASC_UNROLL
     for (int i = 0; i < 7; i++) r[i] = (FORM == 1 && i == IA) ? rr[i] : rr[i] + dln[i];
+    if (SCHEME == 1) {           // Abar_{k+1}' dlambda_{k+1} = dlambda_{k+1} + cs * F_z(z_k)' dlambda_{k+1}
+      double t2_[7];
+      fzt_lambda(G, dln, t2_);
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) r[i] += cs * t2_[i];
+    }
     solveAT<FORM>(G, E, cs, r, dl);
     sp[offS] = hot.pick(dl);
     ASC_UNROLL
@@ -1465,8 +1503,8 @@ int pipeline_run(const ascent_params *dp, long batch, int K, int scheme, int for
   // for the host inside a burst.  A lane needs at most max_iter+1 accepted trial points plus a bounded number
   // of rejected trials and refactorisations per iteration, so the loop terminates.
   // the 16-lanes-per-NLP factorisation pays while the chip has idle SIMDs (see q_factor_wide)
-  bool wide = scheme == 0 && batch <= 8192;
-  if (const char *e = getenv("ASCENT_FACTOR")) wide = scheme == 0 && e[0] == 'w';
+  bool wide = batch <= 8192;
+  if (const char *e = getenv("ASCENT_FACTOR")) wide = e[0] == 'w';
   int burst = 4;
   if (const char *e = getenv("ASCENT_ROUNDS_PER_SYNC")) { const int v = atoi(e); if (v >= 1 && v <= 64) burst = v; }
 #define ASC_LAUNCH(KERNEL, GRID, ...)                                                                               \
@@ -1481,21 +1519,21 @@ int pipeline_run(const ascent_params *dp, long batch, int K, int scheme, int for
       ASC_LAUNCH(q_trial_eval, dim3(tiles, g.nch), dp, batch, g, ws);
       PCHK(hipMemsetAsync(counters, 0, 3 * sizeof(int), stream));
       ASC_LAUNCH(q_decide_factor, dim3(tiles), dp, batch, g, ws, max_iter, tol, counters, wide ? 0 : 1);
-      if (wide) {
-        const dim3 wgrid((unsigned)((batch + WIDE_NLP_PER_BLOCK - 1) / WIDE_NLP_PER_BLOCK));
-        if (form == 1) hipLaunchKernelGGL((q_factor_wide<1>), wgrid, dim3(WIDE_THREADS), 0, stream, dp, batch, g, ws, counters);
-        else hipLaunchKernelGGL((q_factor_wide<0>), wgrid, dim3(WIDE_THREADS), 0, stream, dp, batch, g, ws, counters);
-      }
-      if (r == burst - 1) PCHK(hipMemcpyAsync(host_cnt, counters, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
       const dim3 wgrid((unsigned)((batch + WIDE_NLP_PER_BLOCK - 1) / WIDE_NLP_PER_BLOCK));
+#define ASC_LAUNCH_WIDE(KERNEL, ...)                                                                                \
+  do {                                                                                                              \
+    if (form == 1) hipLaunchKernelGGL((KERNEL<0, 1>), wgrid, dim3(WIDE_THREADS), 0, stream, __VA_ARGS__);           \
+    else if (scheme == 1) hipLaunchKernelGGL((KERNEL<1, 0>), wgrid, dim3(WIDE_THREADS), 0, stream, __VA_ARGS__);   \
+    else hipLaunchKernelGGL((KERNEL<0, 0>), wgrid, dim3(WIDE_THREADS), 0, stream, __VA_ARGS__);                     \
+  } while (0)
+      if (wide) ASC_LAUNCH_WIDE(q_factor_wide, dp, batch, g, ws, counters);
+      if (r == burst - 1) PCHK(hipMemcpyAsync(host_cnt, counters, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
       if (!wide) ASC_LAUNCH(q_forward, dim3(tiles), dp, batch, g, ws);
-      else if (form == 1) hipLaunchKernelGGL((q_forward_wide<1>), wgrid, dim3(WIDE_THREADS), 0, stream, dp, batch, g, ws);
-      else hipLaunchKernelGGL((q_forward_wide<0>), wgrid, dim3(WIDE_THREADS), 0, stream, dp, batch, g, ws);
+      else ASC_LAUNCH_WIDE(q_forward_wide, dp, batch, g, ws);
       hipLaunchKernelGGL(q_local, dim3(tiles, g.nch), dim3(WAVE), 0, stream, dp, batch, g, ws);
       if (!wide) ASC_LAUNCH(q_adjoint, dim3(tiles), dp, batch, g, ws);
-      else if (form == 1) hipLaunchKernelGGL((q_adjoint_wide<1>), wgrid, dim3(WIDE_THREADS), 0, stream, dp, batch, g, ws);
-      else hipLaunchKernelGGL((q_adjoint_wide<0>), wgrid, dim3(WIDE_THREADS), 0, stream, dp, batch, g, ws);
-      launches += 5;
+      else ASC_LAUNCH_WIDE(q_adjoint_wide, dp, batch, g, ws);
+      launches += wide ? 6 : 5;
     }
     PCHK(hipStreamSynchronize(stream));
     const int n_pending = host_cnt[0], n_factored = host_cnt[1];   // retrial/refactor lanes; lanes with a step to take

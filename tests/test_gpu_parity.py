@@ -134,18 +134,19 @@ def test_wide_and_one_lane_sweeps_agree(coracle, monkeypatch):
     NLP (DPP row broadcasts + LDS transpose; used for batches <= 8192; ASCENT_FACTOR=lane|wide overrides).  Same
     algorithm, different summation order: identical iteration counts, answers equal to rounding, both equal to
     the oracle; ragged batch sizes exercise partially filled wavefronts and workgroups of the 16-lane kernels."""
-    for B, form, P in ((70, "current", A.sweep_isp_drymass(10, 7)),
-                       (3, "v1", np.repeat(A.AscentParams(r_peri=53108.4, r_apo=53108.4, mass_scalar=2576.0).as_row()[None], 3, 0))):
+    for scheme, form, P in ((0, "current", A.sweep_isp_drymass(10, 7)),
+                            (1, "current", A.sweep_isp_drymass(7, 5)),
+                            (0, "v1", np.repeat(A.AscentParams(r_peri=53108.4, r_apo=53108.4, mass_scalar=2576.0).as_row()[None], 3, 0))):
         out = {}
         for mode in ("lane", "wide"):
             monkeypatch.setenv("ASCENT_PIPELINE", "split")
             monkeypatch.setenv("ASCENT_FACTOR", mode)
-            out[mode] = A.solve_batch(P, NT, tol=1e-9, want_blob=True, formulation=form, max_iter=500)
+            out[mode] = A.solve_batch(P, NT, tol=1e-9, want_blob=True, formulation=form, scheme=scheme, max_iter=500)
             assert np.all(out[mode].status == 0)
         assert np.array_equal(out["lane"].iters, out["wide"].iters)
         assert np.abs(out["lane"].tf - out["wide"].tf).max() <= 1e-12
         assert np.abs(out["lane"].blob - out["wide"].blob).max() <= 1e-6 * np.abs(out["lane"].blob).max()
-        ref = coracle.solve_batch(P, NT, 500, 1e-9, formulation=1 if form == "v1" else 0)
+        ref = coracle.solve_batch(P, NT, 500, 1e-9, formulation=1 if form == "v1" else 0, scheme=scheme)
         assert np.array_equal(out["wide"].iters, ref["iters"])
         assert np.abs(out["wide"].tf - ref["tf"]).max() <= 1e-9 * ref["tf"].max()
     # the inertia-correction path of the 16-lane factorisation (needs a regularised step somewhere in the sweep)
