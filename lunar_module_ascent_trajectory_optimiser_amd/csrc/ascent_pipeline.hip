@@ -430,105 +430,131 @@ ASC_DEV void loadQV(const QTile &t_, int k, InQV &in) {
   in.ru0 = ROW(sp, Q_SC + 1); in.bza = ROW(sp, Q_SC + 2); in.bzm = ROW(sp, Q_SC + 3); in.bu = ROW(sp, Q_SC + 4);
 }
 
+// The per-NLP decisions between two Newton steps: Armijo test of the trial point (walking the halving ladder on
+// rejection), acceptance, convergence test, barrier update.  Shared by q_decide_factor (one lane per NLP, the lane
+// writes) and q_factor_wide (16 lanes per NLP compute it redundantly, lane 0 writes): everything later code needs
+// comes back in registers, because the other lanes of a group must not depend on seeing lane 0's stores.
+struct Decided {
+  int state, cur;          // state to continue with; which iterate buffer is current
+  double mu, dw, rth;      // barrier parameter, primal regularisation, d/dtheta of the Lagrangian
+  Scal s;                  // scalars of the current iterate
+};
+#define WSC(r, v) do { if (writer) SC(r) = (v); } while (0)
+ASC_DEV Decided decide_lane(const QTile &t_, gdbl *sc, const Geo &g, const Der &d, int max_iter, double tol,
+                            int *counters, bool writer) {
+  Decided out;
+  const int state = (int)SC(X_STATE);
+  out.state = state; out.cur = (int)SC(X_CUR); out.mu = SC(X_MU); out.dw = SC(X_DW); out.rth = SC(X_RTH);
+  if (state == ST_DONE) return out;
+  WSC(X_ROUNDS, SC(X_ROUNDS) + 1.0);
+  if (state == ST_FACTORED) {
+    if (writer) atomicAdd(&counters[1], 1);
+    return out;
+  }
+  if (state == ST_FACTOR) {      // refactorisation with a larger delta_w
+    out.s = load_scal(t_, sc, X_S);
+    return out;
+  }
+  const int K = g.K;
+  double mu = out.mu;
+  // ---- reduce the partials of the trial point -------------------------------------------------
+  double rd = 0.0, cinf = 0.0, pmin = 1e300, pmax = -1e300, l1 = 0.0, zsum = 0.0, rth = 1.0, c1 = 0.0, sl = 0.0;
+  for (int c = g.nch - 1; c >= 0; c--) {
+    const gdbl *pp = part_base(t_, g, c);
+    rd = fmax(rd, ROW(pp, 0)); cinf = fmax(cinf, ROW(pp, 1));
+    pmin = fmin(pmin, ROW(pp, 2)); pmax = fmax(pmax, ROW(pp, 3));
+    l1 += ROW(pp, 4); zsum += ROW(pp, 5); rth += ROW(pp, 6); c1 += ROW(pp, 7); sl += ROW(pp, 8);
+  }
+  const bool first = SC(X_FIRST) != 0.0;
+  const Scal st = load_scal(t_, sc, X_T);
+  double nu_pen = SC(X_NUP), iters = SC(X_ITERS);
+  if (!first) {   // Armijo test on the l1 merit function
+    const double alpha = SC(X_ALPHA), phi0 = SC(X_PHI0), Dm = SC(X_DM);
+    const double phit = st.th - mu * sl + nu_pen * c1;
+    if (!(isfinite(phit) && phit <= phi0 + 1e-8 * alpha * Dm + 2.220446049250313e-15 * fabs(phi0))) {
+      // rejected: walk the halving sequence alpha/2, alpha/4, ... through the ladder values computed on the
+      // side; the first acceptable one (or, failing that, alpha/16) is what gets evaluated in the next round
+      int ls = (int)SC(X_LS) + 1;
+      double an = 0.5 * alpha;
+      const double th0 = SC(X_S + S_TH), dth0 = SC(X_D + S_TH);
+      ASC_UNROLL
+      for (int j = 0; j < NLAD; j++) {
+        double c1j = 0.0, slj = 0.0;
+        for (int c = g.nch - 1; c >= 0; c--) {
+          const gdbl *pp = part_base(t_, g, c);
+          c1j += ROW(pp, 9 + 2 * j); slj += ROW(pp, 10 + 2 * j);
+        }
+        const double thj = th0 + an * dth0;
+        const double phij = thj - mu * slj + nu_pen * c1j;
+        if (isfinite(phij) && phij <= phi0 + 1e-8 * an * Dm + 2.220446049250313e-15 * fabs(phi0)) break;
+        if (ls >= 40) break;
+        an *= 0.5; ls++;
+      }
+      WSC(X_LS, ls);
+      if (ls >= 40) {
+        WSC(X_STATUS, ASCENT_LINESEARCH_FAILED); WSC(X_STATE, ST_DONE);
+        out.state = ST_DONE;
+      } else {
+        WSC(X_ALPHA, an);                // stays in ST_TRIAL: evaluated in full in the next round
+        if (writer) atomicAdd(&counters[0], 1);
+      }
+      return out;
+    }
+    iters += 1.0;
+    WSC(X_ITERS, iters);
+  }
+  // ---- accepted: the trial point is the iterate ---------------------------------------------------
+  if (writer) store_scal(t_, sc, X_S, st);
+  out.s = st; out.cur = 1 - out.cur; out.rth = rth; out.dw = 0.0;
+  WSC(X_CUR, (double)out.cur);
+  WSC(X_FIRST, 0.0); WSC(X_C1, c1); WSC(X_SL, sl); WSC(X_LS, 0.0); WSC(X_RTH, rth);
+  ErrParts e;
+  e.rd = fmax(rd, fabs(rth - st.zlt + st.zut));
+  e.rd = fmax(e.rd, fmax(fabs(-st.nu1 - st.zs1), fabs(-st.nu2 - st.zs2)));
+  e.cinf = cinf;
+  const double pr[4] = {(st.th - d.tlb) * st.zlt, (d.tub - st.th) * st.zut, st.s1 * st.zs1, st.s2 * st.zs2};
+  ASC_UNROLL
+  for (int j = 0; j < 4; j++) { pmin = fmin(pmin, pr[j]); pmax = fmax(pmax, pr[j]); }
+  e.pmin = pmin; e.pmax = pmax;
+  l1 += fabs(st.nu3) + fabs(st.nu1) + fabs(st.nu2);
+  zsum += st.zlt + st.zut + st.zs1 + st.zs2;
+  e.sd = fmax(100.0, (l1 + zsum) / (double)(13 * K + 7)) * 0.01;
+  if (e.err(0.0) <= tol) {
+    WSC(X_STATUS, ASCENT_CONVERGED); WSC(X_STATE, ST_DONE);
+    out.state = ST_DONE;
+    return out;
+  }
+  if ((int)iters >= max_iter) {
+    WSC(X_STATUS, ASCENT_MAX_ITER); WSC(X_STATE, ST_DONE);
+    out.state = ST_DONE;
+    return out;
+  }
+  while (mu > tol * 0.1 && e.err(mu) <= 10.0 * mu) {
+    mu = fmax(tol * 0.1, fmin(0.2 * mu, mu * sqrt(mu)));
+    nu_pen = 1.0;
+  }
+  WSC(X_MU, mu); WSC(X_NUP, nu_pen); WSC(X_DW, 0.0);
+  out.mu = mu;
+  out.state = ST_FACTOR;
+  return out;
+}
+
 template <int SCHEME, int FORM>
 __global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *params, long batch, Geo g,
-                                                        double *ws, int max_iter, double tol, int *counters,
-                                                        int factor_here) {
+                                                        double *ws, int max_iter, double tol, int *counters) {
   const long p = (long)blockIdx.x * WAVE + threadIdx.x;
   if (p >= batch) return;
   const QTile t_((gdbl *)ws + (size_t)blockIdx.x * g.tile_doubles());
   gdbl *sc = scal_base(t_, g);
-  int state = (int)SC(X_STATE);
-  if (state == ST_DONE) return;
-  SC(X_ROUNDS) = SC(X_ROUNDS) + 1.0;
   const Der d = derive(params[p]);
   const int K = g.K;
-  double mu = SC(X_MU);
-  if (state == ST_TRIAL) {
-    // ---- reduce the partials of the trial point -------------------------------------------------
-    double rd = 0.0, cinf = 0.0, pmin = 1e300, pmax = -1e300, l1 = 0.0, zsum = 0.0, rth = 1.0, c1 = 0.0, sl = 0.0;
-    for (int c = g.nch - 1; c >= 0; c--) {
-      const gdbl *pp = part_base(t_, g, c);
-      rd = fmax(rd, ROW(pp, 0)); cinf = fmax(cinf, ROW(pp, 1));
-      pmin = fmin(pmin, ROW(pp, 2)); pmax = fmax(pmax, ROW(pp, 3));
-      l1 += ROW(pp, 4); zsum += ROW(pp, 5); rth += ROW(pp, 6); c1 += ROW(pp, 7); sl += ROW(pp, 8);
-    }
-    const bool first = SC(X_FIRST) != 0.0;
-    const Scal st = load_scal(t_, sc, X_T);
-    double nu_pen = SC(X_NUP);
-    if (!first) {   // Armijo test on the l1 merit function
-      const double alpha = SC(X_ALPHA), phi0 = SC(X_PHI0), Dm = SC(X_DM);
-      const double phit = st.th - mu * sl + nu_pen * c1;
-      if (!(isfinite(phit) && phit <= phi0 + 1e-8 * alpha * Dm + 2.220446049250313e-15 * fabs(phi0))) {
-        // rejected: walk the halving sequence alpha/2, alpha/4, ... through the ladder values computed on the
-        // side; the first acceptable one (or, failing that, alpha/16) is what gets evaluated in the next round
-        int ls = (int)SC(X_LS) + 1;
-        double an = 0.5 * alpha;
-        ASC_UNROLL
-        for (int j = 0; j < NLAD; j++) {
-          double c1j = 0.0, slj = 0.0;
-          for (int c = g.nch - 1; c >= 0; c--) {
-            const gdbl *pp = part_base(t_, g, c);
-            c1j += ROW(pp, 9 + 2 * j); slj += ROW(pp, 10 + 2 * j);
-          }
-          const double thj = SC(X_S + S_TH) + an * SC(X_D + S_TH);
-          const double phij = thj - mu * slj + nu_pen * c1j;
-          if (isfinite(phij) && phij <= phi0 + 1e-8 * an * Dm + 2.220446049250313e-15 * fabs(phi0)) break;
-          if (ls >= 40) break;
-          an *= 0.5; ls++;
-        }
-        SC(X_LS) = ls;
-        if (ls >= 40) {
-          SC(X_STATUS) = ASCENT_LINESEARCH_FAILED; SC(X_STATE) = ST_DONE;
-        } else {
-          SC(X_ALPHA) = an;                // stays in ST_TRIAL: evaluated in full in the next round
-          atomicAdd(&counters[0], 1);
-        }
-        return;
-      }
-      SC(X_ITERS) = SC(X_ITERS) + 1.0;
-    }
-    // ---- accepted: the trial point is the iterate ---------------------------------------------------
-    store_scal(t_, sc, X_S, st);
-    SC(X_CUR) = 1.0 - SC(X_CUR);
-    SC(X_FIRST) = 0.0; SC(X_C1) = c1; SC(X_SL) = sl; SC(X_LS) = 0.0; SC(X_RTH) = rth;
-    ErrParts e;
-    e.rd = fmax(rd, fabs(rth - st.zlt + st.zut));
-    e.rd = fmax(e.rd, fmax(fabs(-st.nu1 - st.zs1), fabs(-st.nu2 - st.zs2)));
-    e.cinf = cinf;
-    const double pr[4] = {(st.th - d.tlb) * st.zlt, (d.tub - st.th) * st.zut, st.s1 * st.zs1, st.s2 * st.zs2};
-    ASC_UNROLL
-    for (int j = 0; j < 4; j++) { pmin = fmin(pmin, pr[j]); pmax = fmax(pmax, pr[j]); }
-    e.pmin = pmin; e.pmax = pmax;
-    l1 += fabs(st.nu3) + fabs(st.nu1) + fabs(st.nu2);
-    zsum += st.zlt + st.zut + st.zs1 + st.zs2;
-    e.sd = fmax(100.0, (l1 + zsum) / (double)(13 * K + 7)) * 0.01;
-    if (e.err(0.0) <= tol) {
-      SC(X_STATUS) = ASCENT_CONVERGED; SC(X_STATE) = ST_DONE;
-      return;
-    }
-    if ((int)SC(X_ITERS) >= max_iter) {
-      SC(X_STATUS) = ASCENT_MAX_ITER; SC(X_STATE) = ST_DONE;
-      return;
-    }
-    while (mu > tol * 0.1 && e.err(mu) <= 10.0 * mu) {
-      mu = fmax(tol * 0.1, fmin(0.2 * mu, mu * sqrt(mu)));
-      nu_pen = 1.0;
-    }
-    SC(X_MU) = mu; SC(X_NUP) = nu_pen; SC(X_DW) = 0.0;
-    state = ST_FACTOR;
-  } else if (state == ST_FACTORED) {
-    atomicAdd(&counters[1], 1);
-    return;
-  }
-  if (!factor_here) {   // q_factor_wide follows and factorises the lanes left in ST_FACTOR
-    SC(X_STATE) = ST_FACTOR;
-    return;
-  }
+  const Decided dc = decide_lane(t_, sc, g, d, max_iter, tol, counters, true);
+  if (dc.state != ST_FACTOR) return;
+  const double mu = dc.mu;
   // ---- backward factorisation at the current iterate, primal regularisation dw ---------------------
-  const unsigned oc = buf_off(t_, (int)SC(X_CUR));
-  const Scal s = load_scal(t_, sc, X_S);
-  const double dw = SC(X_DW);
+  const unsigned oc = buf_off(t_, dc.cur);
+  const Scal s = dc.s;
+  const double dw = dc.dw;
   const double hT = (1.0 / K) * d.T, dt = hT * s.th, be = dt * d.alpha, ith = rcp(s.th);
   const double cs = SCHEME == 1 ? 0.5 * dt : dt;
   constexpr int IB = FORM == 1 ? IA : IW;          // the defect row the control enters ...
@@ -671,7 +697,7 @@ __global__ __launch_bounds__(WAVE) void q_decide_factor(const ascent_params *par
   double dth = 0.0, dnu3 = 0.0;
   if (ok) {
     const double itl = rcp(s.th - d.tlb), itu = rcp(d.tub - s.th);
-    const double rthp = SC(X_RTH) + mu * (itu - itl);   // d/dtheta of the barrier Lagrangian
+    const double rthp = dc.rth + mu * (itu - itl);   // d/dtheta of the barrier Lagrangian
     const double sth = s.zlt * itl + s.zut * itu + dw;
     const double a11 = sth - S11, a12 = -S12, a22 = -S22;
     const double b1 = -rthp + S10, b2 = -tm.e3 + S20;
@@ -732,7 +758,7 @@ struct InW {
 
 template <int SCHEME, int FORM>
 __global__ __launch_bounds__(WIDE_THREADS) void q_factor_wide(const ascent_params *params, long batch, Geo g,
-                                                              double *ws, int *counters) {
+                                                              double *ws, int max_iter, double tol, int *counters) {
   __shared__ double lds_t[WIDE_THREADS / 16][7][7];     // [group][column][row]
   __shared__ double lds_d[WIDE_THREADS / 16][2][8];     // [group][rhs][row]
   const int grp = threadIdx.x >> 4, role = threadIdx.x & 15;
@@ -740,13 +766,16 @@ __global__ __launch_bounds__(WIDE_THREADS) void q_factor_wide(const ascent_param
   const unsigned L = (unsigned)(p & (WAVE - 1));
   const QTile t_((gdbl *)ws + (size_t)(blockIdx.x >> 2) * g.tile_doubles(), L);
   gdbl *sc = scal_base(t_, g);
-  if (p >= batch || (int)SC(X_STATE) != ST_FACTOR) return;
+  if (p >= batch) return;
   const Der d = derive(params[p]);
   const int K = g.K;
-  const double mu = SC(X_MU);
-  const unsigned oc = L + (unsigned)((int)SC(X_CUR)) * (21 * WAVE);
-  const Scal s = load_scal(t_, sc, X_S);
-  const double dw = SC(X_DW);
+  // the decisions of the round, computed by all 16 lanes of the NLP, written by lane 0 (no separate launch)
+  const Decided dc = decide_lane(t_, sc, g, d, max_iter, tol, counters, role == 0);
+  if (dc.state != ST_FACTOR) return;
+  const double mu = dc.mu;
+  const unsigned oc = L + (unsigned)dc.cur * (21 * WAVE);
+  const Scal s = dc.s;
+  const double dw = dc.dw;
   const double hT = (1.0 / K) * d.T, dt = hT * s.th, be = dt * d.alpha, ith = rcp(s.th);
   const double cs = SCHEME == 1 ? 0.5 * dt : dt;
   constexpr int IB = FORM == 1 ? IA : IW;
@@ -930,7 +959,7 @@ __global__ __launch_bounds__(WIDE_THREADS) void q_factor_wide(const ascent_param
   double dth = 0.0, dnu3 = 0.0;
   if (ok) {
     const double itl = rcp(s.th - d.tlb), itu = rcp(d.tub - s.th);
-    const double rthp = SC(X_RTH) + mu * (itu - itl);
+    const double rthp = dc.rth + mu * (itu - itl);
     const double sth = s.zlt * itl + s.zut * itu + dw;
     const double a11 = sth - S11, a12 = -S12, a22 = -S22;
     const double b1 = -rthp + S10, b2 = -tm.e3 + S20;
@@ -1518,7 +1547,7 @@ int pipeline_run(const ascent_params *dp, long batch, int K, int scheme, int for
     for (int r = 0; r < burst; r++, round++) {
       ASC_LAUNCH(q_trial_eval, dim3(tiles, g.nch), dp, batch, g, ws);
       PCHK(hipMemsetAsync(counters, 0, 3 * sizeof(int), stream));
-      ASC_LAUNCH(q_decide_factor, dim3(tiles), dp, batch, g, ws, max_iter, tol, counters, wide ? 0 : 1);
+      if (!wide) ASC_LAUNCH(q_decide_factor, dim3(tiles), dp, batch, g, ws, max_iter, tol, counters);
       const dim3 wgrid((unsigned)((batch + WIDE_NLP_PER_BLOCK - 1) / WIDE_NLP_PER_BLOCK));
 #define ASC_LAUNCH_WIDE(KERNEL, ...)                                                                                \
   do {                                                                                                              \
@@ -1526,14 +1555,14 @@ int pipeline_run(const ascent_params *dp, long batch, int K, int scheme, int for
     else if (scheme == 1) hipLaunchKernelGGL((KERNEL<1, 0>), wgrid, dim3(WIDE_THREADS), 0, stream, __VA_ARGS__);   \
     else hipLaunchKernelGGL((KERNEL<0, 0>), wgrid, dim3(WIDE_THREADS), 0, stream, __VA_ARGS__);                     \
   } while (0)
-      if (wide) ASC_LAUNCH_WIDE(q_factor_wide, dp, batch, g, ws, counters);
+      if (wide) ASC_LAUNCH_WIDE(q_factor_wide, dp, batch, g, ws, max_iter, tol, counters);
       if (r == burst - 1) PCHK(hipMemcpyAsync(host_cnt, counters, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
       if (!wide) ASC_LAUNCH(q_forward, dim3(tiles), dp, batch, g, ws);
       else ASC_LAUNCH_WIDE(q_forward_wide, dp, batch, g, ws);
       hipLaunchKernelGGL(q_local, dim3(tiles, g.nch), dim3(WAVE), 0, stream, dp, batch, g, ws);
       if (!wide) ASC_LAUNCH(q_adjoint, dim3(tiles), dp, batch, g, ws);
       else ASC_LAUNCH_WIDE(q_adjoint_wide, dp, batch, g, ws);
-      launches += wide ? 6 : 5;
+      launches += 5;
     }
     PCHK(hipStreamSynchronize(stream));
     const int n_pending = host_cnt[0], n_factored = host_cnt[1];   // retrial/refactor lanes; lanes with a step to take
