@@ -358,8 +358,9 @@ static int kkt_solve(const oder *d, work_t *w, const iter_t *it, double mu) {
       }
       w->kap0[3 * k + j] = k0[j];
     }
-#define BIL(i, j) ({ double a_ = D * k0[i] * k0[j]; for (int l = 0; l < 7; l++) \
-      a_ += 0.5 * (rc[i][l] * (q[j][l] + p[j][l]) + rc[j][l] * (q[i][l] + p[i][l])); a_; })
+#define BIL(i, j) ({ double a_ = D * k0[i] * k0[j]; \
+      for (int l = 0; l < 7; l++) { a_ += 0.5 * (rc[i][l] * (q[j][l] + p[j][l]) + rc[j][l] * (q[i][l] + p[i][l])); } \
+      a_; })
     S10 += BIL(1, 0); S11 += BIL(1, 1); S12 += BIL(1, 2); S20 += BIL(2, 0); S22 += BIL(2, 2);
 #undef BIL
   }
