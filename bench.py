@@ -31,17 +31,22 @@ FP64_PEAK_TFLOPS = 78.6        # MI355X FP64 vector = matrix
 APO_KM = np.linspace(70.0, 105.0, 8)
 
 
-def algorithmic_bytes(iters: np.ndarray, nt: int) -> float:
+def algorithmic_bytes(levels, n_problems: int, nt: int) -> float:
     """B_io = params + full trajectory + (tf,status,iters); B_iter = 21 doubles read +
-    21 written per node per interior-point iteration."""
+    21 written per node per interior-point iteration.  levels = [(nodes, total iterations on that grid), ...]:
+    the iterations of the nested iteration's coarse grid are priced at the coarse grid's size."""
     b_io = 16 * 8 + 10 * nt * 8 + 16
-    b_iter = 2 * 21 * 8 * nt
-    return float(len(iters) * b_io + iters.sum() * b_iter)
+    return float(n_problems * b_io + sum(it * 2 * 21 * 8 * n for n, it in levels))
 
 
-def algorithmic_flops(iters: np.ndarray, nt: int) -> float:
+def algorithmic_flops(levels) -> float:
     """SURVEY.md 8d work-optimal count: ~4e3 flop per node per iteration."""
-    return float(iters.sum() * 4e3 * nt)
+    return float(sum(it * 4e3 * n for n, it in levels))
+
+
+def coarse_nodes_of(nt: int) -> int:
+    """The automatic coarse grid of the nested iteration (include/ascent.h: ascent_opts.coarse_nodes)."""
+    return max(14, (nt + 5) // 11)
 
 
 def rank_params(batch: int, rank: int, world: int) -> np.ndarray:
@@ -172,8 +177,14 @@ def main():
         conv_total = int(t.item())
     if rank == 0:
         k_ms = float(np.mean(kernel_ms))
-        b_alg = algorithmic_bytes(iters, NT)
-        f_alg = algorithmic_flops(iters, NT)
+        # iterations per grid level: `iters` counts both levels of the nested iteration; an untimed solve of the coarse
+        # grid alone (the same first leg, deterministic) gives the split
+        ntc = coarse_nodes_of(NT)
+        coarse = A.solve_batch_torch(P_t, ntc, tol=args.tol, want_traj=False, coarse_nodes=-1, sync=True)
+        it_c = coarse["iters"].cpu().numpy()
+        levels = [(NT, float((iters - it_c).sum())), (ntc, float(it_c.sum()))]
+        b_alg = algorithmic_bytes(levels, len(iters), NT)
+        f_alg = algorithmic_flops(levels)
         achieved = b_alg / (k_ms * 1e-3) / 1e9
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
@@ -192,8 +203,11 @@ def main():
                 "workload": ("BASELINE.json configs[2]: 4096-NLP Isp x dry-mass sweep (64x64, Isp 300-320 s, dry mass 2345-2545 kg)"
                              if B == 4096 else f"{B}-NLP sweep per GPU") + ", N=200 nodes, backward Euler (reference NODES=2)",
                 "batch_per_gpu": B, "global_batch": B * world, "n_nodes": NT, "tol": args.tol,
-                "start": "cold (built-in straight-line guess, mu0=0.1)", "parallelism": f"problem-sharded x{world}, gather only",
+                "start": f"cold (built-in straight-line guess, mu0=0.1) on a {ntc}-node grid, prolonged to the {NT}-node grid "
+                         "(nested iteration, part of the solver and of the timed step)",
+                "parallelism": f"problem-sharded x{world}, gather only",
                 "iterations_min_mean_max": [int(iters.min()), float(iters.mean()), int(iters.max())],
+                "iterations_mean_by_grid": {str(NT): float((iters - it_c).mean()), str(ntc): float(it_c.mean())},
                 "converged": conv_total, "of": B * world,
             },
             "roofline": {

@@ -59,7 +59,11 @@ typedef struct ascent_opts {
                           1 = v1 script (PDF p26-28): the angle itself is the MV -- carried in
                               the same arrays: angle = (angle_ub/2)(u+1), angledot = 0, and the
                               `angledoubledot` field holds that normalised control u            */
-  int32_t reserved;    /* must be 0                                                       */
+  int32_t coarse_nodes; /* nested iteration for cold starts (warm_start == 0): the NLP is first solved on a coarse
+                           grid, that primal-dual solution is prolonged to the n_nodes grid and warm-starts it.
+                           0 = automatic (grids of >= 64 nodes; coarse grid = max(14, (n_nodes+5)/11) nodes,
+                           recursively), -1 = off (single grid), > 0 = that many coarse nodes (two levels).
+                           iters_out counts the iterations of all levels.                              */
 } ascent_opts;
 
 enum ascent_status {           /* function return codes */

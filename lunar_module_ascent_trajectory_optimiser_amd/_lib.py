@@ -26,7 +26,7 @@ class AscentOptsC(C.Structure):
     """struct ascent_opts (include/ascent.h)."""
     _fields_ = [("n_nodes", C.c_int32), ("scheme", C.c_int32), ("max_iter", C.c_int32),
                 ("warm_start", C.c_int32), ("tol", C.c_double), ("mu_init", C.c_double),
-                ("formulation", C.c_int32), ("reserved", C.c_int32)]
+                ("formulation", C.c_int32), ("coarse_nodes", C.c_int32)]
 
 
 SYMBOLS = ("ascent_version", "ascent_device_count", "ascent_strerror", "ascent_solve_batch",

@@ -109,6 +109,9 @@ __global__ __launch_bounds__(WAVE) void q_init(const ascent_params *params, long
   const int K = g.K;
   gdbl *sc = scal_base(t_, g);
   Scal s;
+  // a guess whose theta is not positive means "no guess for this problem" (nested iteration: the coarse solve failed)
+  const int asked_warm = warm;
+  if (warm && !(guess[(21L * K + S_TH) * batch + p] > 0.0)) warm = 0;
   if (warm) {
     for (int k = 0; k < K; k++) {
       gdbl *sp = t_.st(k);
@@ -176,7 +179,7 @@ __global__ __launch_bounds__(WAVE) void q_init(const ascent_params *params, long
   for (int r = 0; r < NSCAL; r++) SC(r) = 0.0;
   store_scal(t_, sc, X_S, s);
   SC(X_STATE) = ST_TRIAL; SC(X_FIRST) = 1.0; SC(X_STATUS) = ASCENT_MAX_ITER;
-  SC(X_MU) = mu_init; SC(X_NUP) = 1.0;
+  SC(X_MU) = (asked_warm && !warm) ? 0.1 : mu_init; SC(X_NUP) = 1.0;
 }
 
 // per-lane iterate buffer: lanes advance asynchronously, so which of the two iterate buffers holds a

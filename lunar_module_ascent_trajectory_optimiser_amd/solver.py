@@ -25,11 +25,11 @@ SCHEMES = {"backward_euler": 0, "trapezoid": 1}
 FORMULATIONS = {"current": 0, "v1": 1}
 
 
-def _opts(nt, max_iter, tol, warm_start, mu_init, scheme=0, formulation=0):
+def _opts(nt, max_iter, tol, warm_start, mu_init, scheme=0, formulation=0, coarse_nodes=0):
     scheme = SCHEMES.get(scheme, scheme)
     formulation = FORMULATIONS.get(formulation, formulation)
     return _lib.AscentOptsC(n_nodes=nt, scheme=int(scheme), max_iter=max_iter, warm_start=warm_start, tol=tol,
-                            mu_init=mu_init, formulation=int(formulation), reserved=0)
+                            mu_init=mu_init, formulation=int(formulation), coarse_nodes=int(coarse_nodes))
 
 
 def _ptr(a):
@@ -99,11 +99,13 @@ class BatchResult:
 
 def solve_batch(params, nt: int = 200, tol: float = 1e-9, max_iter: int = 300, guess: np.ndarray | None = None,
                 warm_start: int | None = None, mu_init: float = 0.0, device: int = 0, want_traj: bool = True,
-                want_blob: bool = False, scheme=0, formulation=0) -> BatchResult:
+                want_blob: bool = False, scheme=0, formulation=0, coarse_nodes: int = 0) -> BatchResult:
     """Solve a batch of ascent NLPs on one GPU.  params: AscentParams | list | (batch,16) array.
     guess: (21K+10, batch) blob, with warm_start 1 (primal only) or 2 (primal-dual).
     scheme: 0 / "backward_euler" (the reference's NODES=2) or 1 / "trapezoid" (control held over the step).
-    formulation: 0 / "current" or 1 / "v1" (the PDF appendix script: the angle is the MV; see include/ascent.h)."""
+    formulation: 0 / "current" or 1 / "v1" (the PDF appendix script: the angle is the MV; see include/ascent.h).
+    coarse_nodes: nested iteration for cold starts (0 automatic, -1 single grid, > 0 explicit coarse grid);
+    `iters` then counts the iterations of all grid levels."""
     L = _lib.load()
     P = pack(params)
     B = P.shape[0]
@@ -120,7 +122,7 @@ def solve_batch(params, nt: int = 200, tol: float = 1e-9, max_iter: int = 300, g
     tf = np.empty(B)
     status = np.empty(B, dtype=np.int32)
     iters = np.empty(B, dtype=np.int32)
-    o = _opts(nt, max_iter, tol, warm_start, mu_init, scheme, formulation)
+    o = _opts(nt, max_iter, tol, warm_start, mu_init, scheme, formulation, coarse_nodes)
     _lib.check(L.ascent_solve_batch(_ptr(P), B, C.byref(o), _ptr(guess), _ptr(traj), _ptr(tf), _ptr(status),
                                     _ptr(iters), _ptr(blob), device, None, 0))
     return BatchResult(P, nt, traj, tf, status, iters, blob, L.ascent_last_kernel_ms(device))
@@ -159,7 +161,7 @@ def kkt_step(params, iterate: np.ndarray, mu, delta_w, nt: int = 200, device: in
 
 def solve_batch_torch(params_t, nt: int = 200, tol: float = 1e-9, max_iter: int = 300, guess_t=None,
                       warm_start: int = 0, mu_init: float = 0.0, want_traj: bool = True, want_blob: bool = False,
-                      out: dict | None = None, sync: bool = False) -> dict:
+                      out: dict | None = None, sync: bool = False, coarse_nodes: int = 0) -> dict:
     """Device-resident variant: `params_t` is a torch float64 CUDA tensor (batch,16); all outputs are
     torch CUDA tensors (allocated here unless passed in `out`).  Enqueues on torch's current stream
     and returns without waiting unless sync=True.  torch is only the owner of device memory/streams."""
@@ -181,7 +183,7 @@ def solve_batch_torch(params_t, nt: int = 200, tol: float = 1e-9, max_iter: int 
     iters = buf("iters", (B,), torch.int32)
     traj = buf("traj", (10, nt, B), torch.float64) if want_traj else None
     blob = buf("blob", (rows, B), torch.float64) if want_blob else None
-    o = _opts(nt, max_iter, tol, warm_start, mu_init)
+    o = _opts(nt, max_iter, tol, warm_start, mu_init, coarse_nodes=coarse_nodes)
     stream = torch.cuda.current_stream(dev).cuda_stream
     _lib.check(L.ascent_solve_batch(params_t.data_ptr(), B, C.byref(o),
                                     guess_t.data_ptr() if guess_t is not None else None,

@@ -508,25 +508,37 @@ static double g_mu0 = 0.1, g_keps = 10.0, g_kmu = 0.2, g_thmu = 1.5;
 void oracle_set_barrier_schedule(double mu0, double keps, double kmu, double thmu) { g_mu0 = mu0; g_keps = keps; g_kmu = kmu; g_thmu = thmu; }
 
 /* one NLP.  blob: in = initial guess (primal part used) if use_guess, out = solution iterate. */
-static int solve_one(const oparams *prm, int nt, int max_iter, double tol, int use_guess, double *blob,
+/* warm: 0 = built-in cold-start guess, 1 = primal part of the blob, 2 = the full primal-dual blob (multipliers and
+ * slacks kept, floored away from zero).  A blob whose theta is not positive is treated as "no guess" (that is how the
+ * nested iteration marks problems whose coarse solve failed).  mu0 <= 0: 0.1 cold, 1e-4 warm. */
+static int solve_one(const oparams *prm, int nt, int max_iter, double tol, int warm, double mu0, double *blob,
                      int *iters_out, int *nreg_out) {
   int K = nt - 1; oder d; derive(prm, &d);
   work_t *w = work_new(K);
   iter_t it, tr, st; view(blob, K, &it); view(w->trial, K, &tr); view(w->step, K, &st);
-  if (!use_guess) { memset(blob, 0, BLOB(K) * 8); initial_guess(&d, K, w->h, &it); }
+  const int asked_warm = warm;
+  if (warm && !(it.sc[S_TH] > 0.0)) warm = 0;
+  if (!warm) { memset(blob, 0, BLOB(K) * 8); initial_guess(&d, K, w->h, &it); }
+  const double s1g = it.sc[S_S1], s2g = it.sc[S_S2];
   it.sc[S_S1] = it.sc[S_S2] = 0.0;
   constraints(&d, K, w->h, &it, w->c);
   it.sc[S_S1] = fmax(w->c[7 * K + 1], 1e-2); it.sc[S_S2] = fmax(w->c[7 * K + 2], 1e-4);
   for (int k = 0; k < K; k++) {
     double *z = it.z + 7 * k;
     z[IA] = push(z[IA], 0.0, d.aub); z[IM] = push(z[IM], 0.0, 1.0); it.u[k] = push(it.u[k], -1.0, 1.0);
-    for (int b = 0; b < 6; b++) it.zb[6 * k + b] = 1.0;
+    for (int b = 0; b < 6; b++) it.zb[6 * k + b] = warm == 2 ? fmax(it.zb[6 * k + b], 1e-12) : 1.0;
   }
   it.sc[S_TH] = push(it.sc[S_TH], d.tlb, d.tub);
-  it.sc[S_S1] = fmax(it.sc[S_S1], 1e-2); it.sc[S_S2] = fmax(it.sc[S_S2], 1e-2);
-  it.sc[S_ZLT] = it.sc[S_ZUT] = it.sc[S_ZS1] = it.sc[S_ZS2] = 1.0;
-  memset(it.lam, 0, 7 * K * 8); it.sc[S_NU3] = it.sc[S_NU1] = it.sc[S_NU2] = 0.0;
-  double mu = g_mu0, nu_pen = 1.0, dw_last = 0.0;
+  if (warm == 2) {
+    it.sc[S_S1] = fmax(s1g, 1e-10); it.sc[S_S2] = fmax(s2g, 1e-10);
+    it.sc[S_ZLT] = fmax(it.sc[S_ZLT], 1e-12); it.sc[S_ZUT] = fmax(it.sc[S_ZUT], 1e-12);
+    it.sc[S_ZS1] = fmax(it.sc[S_ZS1], 1e-12); it.sc[S_ZS2] = fmax(it.sc[S_ZS2], 1e-12);
+  } else {
+    it.sc[S_S1] = fmax(it.sc[S_S1], 1e-2); it.sc[S_S2] = fmax(it.sc[S_S2], 1e-2);
+    it.sc[S_ZLT] = it.sc[S_ZUT] = it.sc[S_ZS1] = it.sc[S_ZS2] = 1.0;
+    memset(it.lam, 0, 7 * K * 8); it.sc[S_NU3] = it.sc[S_NU1] = it.sc[S_NU2] = 0.0;
+  }
+  double mu = (asked_warm && !warm) ? g_mu0 : mu0 > 0.0 ? mu0 : (warm ? 1e-4 : g_mu0), nu_pen = 1.0, dw_last = 0.0;
   int status = ST_MAXITER, iters = 0, nreg = 0;
   for (int iter = 0; iter < max_iter; iter++) {
     double e0 = kkt_error(&d, w, &it, 0.0);
@@ -654,9 +666,64 @@ double oracle_kkt_error(const double *params, int nt, const double *blob, double
   return e;
 }
 
+/* ---- nested iteration (mesh continuation) ------------------------------------------------------------------
+ * A cold start on a grid of >= 64 nodes first solves the same NLP on a grid of about a tenth of the nodes,
+ * prolongs that primal-dual solution to the fine grid (linear in tau; node 0 is the fixed initial state; bound
+ * multipliers scale with the step) and warm-starts the fine solve from it with mu0 = 1e-5.  Recursive in the
+ * automatic mode.  A problem whose coarse solve does not converge starts cold on the fine grid. */
+static int coarse_of(int nt) { int c = (nt + 5) / 11; return c < 14 ? 14 : c; }
+#define NESTED_MIN_NODES 64
+#define NESTED_MU0 1e-5
+
+static void prolong(const double *bc, int Kc, double *bf, int Kf) {
+  iter_t c, f; view((double *)bc, Kc, &c); view(bf, Kf, &f);
+  const double zsc = (double)Kc / (double)Kf;
+  for (int k = 0; k < Kf; k++) {
+    const double x = (double)(k + 1) / (double)Kf * (double)Kc;
+    int j = (int)x; if (j > Kc - 1) j = Kc - 1;
+    const double wt = x - (double)j;
+    const int ja = j ? j - 1 : 0;                 /* coarse record of the left node (node 0 has none) */
+    for (int i = 0; i < 7; i++) {
+      const double a = j ? c.z[7 * ja + i] : ((g_form == 1 && i == IA) ? c.z[i] : 0.0), b = c.z[7 * j + i];
+      f.z[7 * k + i] = fma(wt, b - a, a);
+      const double la = c.lam[7 * ja + i], lb = c.lam[7 * j + i];
+      f.lam[7 * k + i] = fma(wt, lb - la, la);
+    }
+    { const double a = c.u[ja], b = c.u[j]; f.u[k] = fma(wt, b - a, a); }
+    for (int b6 = 0; b6 < 6; b6++) {
+      const double a = c.zb[6 * ja + b6], b = c.zb[6 * j + b6];
+      f.zb[6 * k + b6] = fma(wt, b - a, a) * zsc;
+    }
+  }
+  memcpy(f.sc, c.sc, 10 * 8);
+}
+
+/* blob: out = solution on the nt-grid.  coarse: 0 automatic, -1 single grid, > 0 that many nodes (two levels) */
+static int solve_nested(const oparams *prm, int nt, int max_iter, double tol, int coarse, double *blob, int *iters_out) {
+  int nc = coarse > 0 ? coarse : coarse_of(nt);
+  if (coarse == -1 || (coarse == 0 && nt < NESTED_MIN_NODES) || nc >= nt || nc < 3)
+    return solve_one(prm, nt, max_iter, tol, 0, 0.0, blob, iters_out, 0);
+  double *bc = malloc(BLOB(nc - 1) * 8);
+  int itc = 0, itf = 0;
+  const int stc = solve_nested(prm, nc, max_iter, tol, coarse > 0 ? -1 : 0, bc, &itc);
+  int warm = 0;
+  if (stc == ST_CONVERGED) { prolong(bc, nc - 1, blob, nt - 1); warm = 2; }
+  free(bc);
+  const int st = solve_one(prm, nt, max_iter, tol, warm, NESTED_MU0, blob, &itf, 0);
+  *iters_out = itc + itf;
+  return st;
+}
+
+static int g_coarse = 0;     /* 0 automatic nested iteration, -1 single grid, > 0 explicit coarse grid */
+void oracle_set_coarse_nodes(int c) { g_coarse = c; }
+static double g_warm_mu0 = 0.0; static int g_warm_mode = 1;
+void oracle_set_warm_start(int mode, double mu0) { g_warm_mode = mode; g_warm_mu0 = mu0; }
+void oracle_prolong(const double *blob_c, int nt_c, double *blob_f, int nt_f) { prolong(blob_c, nt_c - 1, blob_f, nt_f - 1); }
+
 /* batch solve. params [batch][16]; traj_out [batch][10][nt] with fields
  * x y xdot ydot xdoubledot ydoubledot angle angledot angledoubledot mass (reference .value lists);
- * blob_out (optional) [batch][blob] full primal-dual solution. */
+ * blob_out (optional) [batch][blob] full primal-dual solution.  With a guess: warm start (oracle_set_warm_start:
+ * mode 1 primal / 2 primal-dual, mu0); without: cold start, nested iteration per oracle_set_coarse_nodes. */
 int oracle_solve_batch(const double *params, int batch, int nt, int max_iter, double tol,
                        const double *guess_blob_or_null, double *traj_out, double *tf_out,
                        int *status_out, int *iters_out, double *blob_out_or_null) {
@@ -664,9 +731,13 @@ int oracle_solve_batch(const double *params, int batch, int nt, int max_iter, do
   for (int b = 0; b < batch; b++) {
     const oparams *prm = (const oparams *)(params + 16 * b);
     double *blob = malloc(BLOB(K) * 8);
-    if (guess_blob_or_null) memcpy(blob, guess_blob_or_null + (size_t)b * BLOB(K), BLOB(K) * 8);
-    int iters = 0;
-    int st = solve_one(prm, nt, max_iter, tol, guess_blob_or_null != 0, blob, &iters, 0);
+    int iters = 0, st;
+    if (guess_blob_or_null) {
+      memcpy(blob, guess_blob_or_null + (size_t)b * BLOB(K), BLOB(K) * 8);
+      st = solve_one(prm, nt, max_iter, tol, g_warm_mode, g_warm_mu0, blob, &iters, 0);
+    } else {
+      st = solve_nested(prm, nt, max_iter, tol, g_coarse, blob, &iters);
+    }
     status_out[b] = st; iters_out[b] = iters;
     iter_t it; view(blob, K, &it);
     tf_out[b] = it.sc[S_TH];

@@ -88,10 +88,16 @@ def accel(params16, x, y, a, m, px, py):
     return ax, ay, gax, gay, H
 
 
-def solve_batch(params, nt=200, max_iter=300, tol=1e-9, guess_blob=None, want_blob=False, scheme=0, formulation=0):
-    """params: (batch,16).  Returns dict(traj (batch,10,nt), tf, status, iters[, blob])."""
+def solve_batch(params, nt=200, max_iter=300, tol=1e-9, guess_blob=None, want_blob=False, scheme=0, formulation=0,
+                coarse_nodes=0, warm_start=1, mu_init=0.0):
+    """params: (batch,16).  Returns dict(traj (batch,10,nt), tf, status, iters[, blob]).
+    Cold starts use the nested iteration (coarse_nodes: 0 automatic, -1 single grid, > 0 explicit coarse grid);
+    with guess_blob (batch, blob) it is a warm start (1 primal, 2 primal-dual; mu_init <= 0: 1e-4).
+    iters counts the iterations of all grid levels."""
     lib().oracle_set_scheme(int(scheme))
     lib().oracle_set_formulation(int(formulation))
+    lib().oracle_set_coarse_nodes(int(coarse_nodes))
+    lib().oracle_set_warm_start(int(warm_start), C.c_double(mu_init))
     params = np.ascontiguousarray(np.atleast_2d(params), dtype=np.float64)
     B = params.shape[0]
     traj = np.zeros((B, 10, nt))
@@ -109,3 +115,12 @@ def solve_batch(params, nt=200, max_iter=300, tol=1e-9, guess_blob=None, want_bl
     if want_blob:
         out["blob"] = blob
     return out
+
+
+def prolong(blob_c, nt_c, nt_f, formulation=0):
+    """Prolongation of one primal-dual blob from an nt_c-node grid to an nt_f-node grid (nested iteration)."""
+    lib().oracle_set_formulation(int(formulation))
+    bc = np.ascontiguousarray(blob_c, dtype=np.float64)
+    bf = np.zeros(blob_size(nt_f))
+    lib().oracle_prolong(_p(bc), int(nt_c), _p(bf), int(nt_f))
+    return bf

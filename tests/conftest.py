@@ -41,7 +41,7 @@ def random_interior_blob(nt, seed, p16, coracle):
     """A strictly interior primal-dual iterate: a few oracle IP iterations from the cold start,
     then multipliers perturbed (seeded)."""
     rng = np.random.default_rng(seed)
-    r = coracle.solve_batch(p16[None], nt, 3 + seed % 4, 1e-9, want_blob=True)
+    r = coracle.solve_batch(p16[None], nt, 3 + seed % 4, 1e-9, want_blob=True, coarse_nodes=-1)
     blob = r["blob"][0].copy()
     K = nt - 1
     blob[8 * K:15 * K] += 0.05 * rng.standard_normal(7 * K)           # lambda

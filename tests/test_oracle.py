@@ -132,9 +132,10 @@ def test_c_accel_matches_numpy(coracle):
         assert np.allclose(r, g, rtol=1e-12, atol=1e-13)
 
 
-def test_c_oracle_agrees_with_numpy_oracle(numpy_nominal, nominal_oracle_solution):
+def test_c_oracle_agrees_with_numpy_oracle(numpy_nominal, nominal_oracle_solution, coracle):
     nlp, v, _, _ = numpy_nominal
-    p16, r = nominal_oracle_solution
+    p16, _ = nominal_oracle_solution
+    r = coracle.solve_batch(p16[None], 200, 300, 1e-9, coarse_nodes=-1)      # single grid, as the numpy oracle
     assert abs(v[nlp.itf] - r["tf"][0]) <= 1e-10 * r["tf"][0]
     o, tr = nlp.outputs(v), r["traj"][0]
     assert np.abs(o["x"] - tr[0]).max() < 1e-9 and np.abs(o["y"] - tr[1]).max() < 1e-9
@@ -202,7 +203,7 @@ def test_trapezoid_scheme_numpy_and_c_agree_with_the_survey_probe(coracle):
     assert abs(o["final_time"] - 435.22715) < 2e-3
     assert abs(o["final_y"] - (-6072.59)) < 1.0 and abs(o["final_x"] - (-287967.39)) < 2.0
     p16 = coracle.pack_params(Params())
-    r = coracle.solve_batch(p16[None], 200, 300, 1e-9, scheme=1)
+    r = coracle.solve_batch(p16[None], 200, 300, 1e-9, scheme=1, coarse_nodes=-1)     # single grid, as the numpy oracle
     coracle.set_scheme(0)
     assert r["status"][0] == 0 and abs(r["tf"][0] - v[nlp.itf]) <= 1e-10 * v[nlp.itf]
     assert np.abs(o["x"] - r["traj"][0][0]).max() < 1e-8
@@ -250,7 +251,7 @@ def test_c_oracle_v1_embedding_matches_numpy_v1_and_golden(coracle, golden):
     numpy oracle restates v1 natively with 5 states and the angle as the control.  Same optimum."""
     P = v1_params()
     p16 = coracle.pack_params(P)
-    r = coracle.solve_batch(p16[None], 200, 500, 1e-9, formulation=1)
+    r = coracle.solve_batch(p16[None], 200, 500, 1e-9, formulation=1, coarse_nodes=-1)  # single grid, as the numpy oracle
     coracle.set_formulation(0)
     assert r["status"][0] == 0
     assert abs(r["tf"][0] * 470 - golden["v1"]["final_time"]) <= 1e-4 * golden["v1"]["final_time"]
@@ -261,3 +262,32 @@ def test_c_oracle_v1_embedding_matches_numpy_v1_and_golden(coracle, golden):
     o = nlp.outputs(v)
     assert np.abs(o["x"] - r["traj"][0][0]).max() < 1e-7 and np.abs(o["angle"][1:] - r["traj"][0][6][1:]).max() < 1e-7
     assert np.abs(r["traj"][0][7]).max() == 0.0                       # angledot slot stays zero
+
+
+def test_c_oracle_nested_iteration_agrees_with_single_grid():
+    """The nested iteration (coarse solve -> prolongation -> warm-started fine solve) converges to the same KKT point
+    as the single-grid cold start; the prolongation reproduces functions that are linear in tau exactly."""
+    from oracle import c_oracle as co
+    import lunar_module_ascent_trajectory_optimiser_amd as A
+    S = A.sweep_isp_drymass(3, 3)
+    a = co.solve_batch(S, 200, 300, 1e-9, coarse_nodes=-1)
+    b = co.solve_batch(S, 200, 300, 1e-9)
+    c = co.solve_batch(S, 200, 300, 1e-9, coarse_nodes=30)
+    assert np.all(a["status"] == 0) and np.all(b["status"] == 0) and np.all(c["status"] == 0)
+    assert np.abs(a["tf"] - b["tf"]).max() <= 2e-9 and np.abs(a["tf"] - c["tf"]).max() <= 2e-9
+    for f in (0, 1, 2, 3, 6, 9):     # states; the control of the singular arc is only weakly determined at tol 1e-9
+        assert np.abs(a["traj"][:, f] - b["traj"][:, f]).max() <= 1e-4 * np.abs(a["traj"][:, f]).max()
+    Kc, Kf = 10, 37
+    blob = np.zeros(co.blob_size(Kc + 1))
+    tau = np.arange(1, Kc + 1) / Kc
+    for i in range(7):
+        blob[i:7 * Kc:7] = (i + 1) * tau                       # states: linear through the origin (node 0 is zero)
+    blob[7 * Kc:8 * Kc] = 0.25 + 0.5 * tau                     # control
+    blob[21 * Kc:] = np.arange(1, 11)
+    f = co.prolong(blob, Kc + 1, Kf + 1)
+    tf_ = np.arange(1, Kf + 1) / Kf
+    for i in range(7):
+        assert np.abs(f[i:7 * Kf:7] - (i + 1) * tf_).max() < 1e-14
+    u = f[7 * Kf:8 * Kf]
+    assert np.abs(u[tf_ >= 1 / Kc] - (0.25 + 0.5 * tf_[tf_ >= 1 / Kc])).max() < 1e-14      # constant before the first coarse node
+    assert np.array_equal(f[21 * Kf:], np.arange(1, 11))
