@@ -98,7 +98,8 @@ ASC_DEV Scal trial_scal(const Der &d, const Scal &s, const Scal &ds, double alph
 }
 
 // ==============================================================================================
-// q_init: initial point into iterate buffer 0, zero step, per-lane state
+// q_init: initial point into iterate buffer 0, zero step, per-lane state.  One wavefront = 64 NLPs x CHUNK steps
+// (grid tiles x chunks); the wavefront of the last chunk also sets the scalars.
 // ==============================================================================================
 __global__ __launch_bounds__(WAVE) void q_init(const ascent_params *params, long batch, Geo g, double *ws,
                                                const double *guess, int warm, double mu_init) {
@@ -106,64 +107,64 @@ __global__ __launch_bounds__(WAVE) void q_init(const ascent_params *params, long
   if (p >= batch) return;
   const QTile t_((gdbl *)ws + (size_t)blockIdx.x * g.tile_doubles());
   const Der d = derive(params[p]);
-  const int K = g.K;
-  gdbl *sc = scal_base(t_, g);
-  Scal s;
+  const int K = g.K, chunk = blockIdx.y;
+  const int k_lo = chunk * CHUNK, k_hi = min(K, k_lo + CHUNK) - 1;
   // a guess whose theta is not positive means "no guess for this problem" (nested iteration: the coarse solve failed)
   const int asked_warm = warm;
   if (warm && !(guess[(21L * K + S_TH) * batch + p] > 0.0)) warm = 0;
-  if (warm) {
-    for (int k = 0; k < K; k++) {
-      gdbl *sp = t_.st(k);
+  // cold start: straight-line states toward a tangential insertion point, u = 0
+  const double tf0 = 0.9, dr = 0.166, aend = 0.5, vp = sqrt(d.vp2), dt0 = (1.0 / K) * d.T * tf0;
+  const double sdr = sin(dr), cdr = cos(dr);
+  const double xf = -d.rhof * sdr, yf = d.rhof * cdr - d.rho0;
+  double zK[7];
+  for (int k = k_lo; k <= k_hi; k++) {
+    gdbl *sp = t_.st(k);
+    double z[7], l[7], zb[6], u;
+    if (warm) {
       ASC_UNROLL
       for (int i = 0; i < 7; i++) {
-        ROW(sp, Q_IT + O_Z + i) = guess[(7L * k + i) * batch + p];
-        ROW(sp, Q_IT + O_L + i) = guess[(8L * K + 7L * k + i) * batch + p];
+        z[i] = guess[(7L * k + i) * batch + p];
+        l[i] = guess[(8L * K + 7L * k + i) * batch + p];
       }
-      ROW(sp, Q_IT + O_U) = guess[(7L * K + k) * batch + p];
+      u = guess[(7L * K + k) * batch + p];
       ASC_UNROLL
-      for (int b = 0; b < 6; b++) ROW(sp, Q_IT + O_ZB + b) = guess[(15L * K + 6L * k + b) * batch + p];
+      for (int b = 0; b < 6; b++) zb[b] = guess[(15L * K + 6L * k + b) * batch + p];
+    } else {
+      const double fr = (double)(k + 1) / K;
+      z[IX] = fr * xf; z[IY] = fr * yf; z[IVX] = -fr * vp * cdr; z[IVY] = -fr * vp * sdr; z[IA] = fr * aend;
+      z[IW] = aend / (K * dt0); z[IM] = d.mrate * dt0 * (k + 1);
+      u = 0.0;
+      if (g.form == 1) {       // v1: the angle is the control: angle = (ub/2)(u+1), no angular rate
+        z[IW] = 0.0;
+        u = z[IA] / (0.5 * d.aub) - 1.0;
+      }
     }
+    z[IA] = push_in(z[IA], 0.0, d.aub);
+    z[IM] = push_in(z[IM], 0.0, 1.0);
+    u = push_in(u, -1.0, 1.0);
+    ASC_UNROLL
+    for (int b = 0; b < 6; b++) zb[b] = warm == 2 ? fmax(zb[b], 1e-12) : 1.0;
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) l[i] = warm == 2 ? l[i] : 0.0;
+    stn<7>(t_, sp, Q_IT + O_Z, z);
+    ROW(sp, Q_IT + O_U) = u;
+    stn<7>(t_, sp, Q_IT + O_L, l);
+    stn<6>(t_, sp, Q_IT + O_ZB, zb);
+    ASC_UNROLL
+    for (int r = 0; r < 21; r++) ROW(sp, Q_ST + r) = 0.0;
+    if (k == K - 1) cpy<7>(zK, z);
+  }
+  if (k_hi != K - 1) return;
+  // ---- scalars (the wavefront that holds the last step) ----------------------------------------------
+  gdbl *sc = scal_base(t_, g);
+  Scal s;
+  if (warm) {
     const double *gs = guess + (21L * K) * batch + p;
     s.th = gs[S_TH * batch]; s.zlt = gs[S_ZLT * batch]; s.zut = gs[S_ZUT * batch]; s.s1 = gs[S_S1 * batch];
     s.s2 = gs[S_S2 * batch]; s.zs1 = gs[S_ZS1 * batch]; s.zs2 = gs[S_ZS2 * batch]; s.nu3 = gs[S_NU3 * batch];
     s.nu1 = gs[S_NU1 * batch]; s.nu2 = gs[S_NU2 * batch];
-  } else {   // cold start: straight-line states toward a tangential insertion point, u = 0
-    const double tf0 = 0.9, dr = 0.166, aend = 0.5, vp = sqrt(d.vp2), dt = (1.0 / K) * d.T * tf0;
-    const double sdr = sin(dr), cdr = cos(dr);
-    const double xf = -d.rhof * sdr, yf = d.rhof * cdr - d.rho0;
-    for (int k = 0; k < K; k++) {
-      const double fr = (double)(k + 1) / K;
-      gdbl *sp = t_.st(k);
-      const double z[7] = {fr * xf, fr * yf, -fr * vp * cdr, -fr * vp * sdr, fr * aend, aend / (K * dt),
-                           d.mrate * dt * (k + 1)};
-      stn<7>(t_, sp, Q_IT + O_Z, z);
-      ROW(sp, Q_IT + O_U) = 0.0;
-      if (g.form == 1) {       // v1: the angle is the control: angle = (ub/2)(u+1), no angular rate
-        ROW(sp, Q_IT + O_Z + IW) = 0.0;
-        ROW(sp, Q_IT + O_U) = z[IA] / (0.5 * d.aub) - 1.0;
-      }
-    }
+  } else {
     s.th = tf0;
-  }
-  double zK[7];
-  for (int k = 0; k < K; k++) {
-    gdbl *sp = t_.st(k);
-    ROW(sp, Q_IT + O_Z + IA) = push_in(ROW(sp, Q_IT + O_Z + IA), 0.0, d.aub);
-    ROW(sp, Q_IT + O_Z + IM) = push_in(ROW(sp, Q_IT + O_Z + IM), 0.0, 1.0);
-    ROW(sp, Q_IT + O_U) = push_in(ROW(sp, Q_IT + O_U), -1.0, 1.0);
-    if (warm != 2) {
-      ASC_UNROLL
-      for (int b = 0; b < 6; b++) ROW(sp, Q_IT + O_ZB + b) = 1.0;
-      ASC_UNROLL
-      for (int i = 0; i < 7; i++) ROW(sp, Q_IT + O_L + i) = 0.0;
-    } else {
-      ASC_UNROLL
-      for (int b = 0; b < 6; b++) ROW(sp, Q_IT + O_ZB + b) = fmax(ROW(sp, Q_IT + O_ZB + b), 1e-12);
-    }
-    ASC_UNROLL
-    for (int r = 0; r < 21; r++) ROW(sp, Q_ST + r) = 0.0;
-    if (k == K - 1) ldn<7>(t_, sp, Q_IT + O_Z, zK);
   }
   s.th = push_in(s.th, d.tlb, d.tub);
   const Terminal tm = terminal_eval(d, zK);
@@ -1450,45 +1451,49 @@ __global__ __launch_bounds__(WAVE) void q_finish(const ascent_params *params, lo
   const QTile t_((gdbl *)ws + (size_t)blockIdx.x * g.tile_doubles());
   gdbl *sc = scal_base(t_, g);
   const Der d = derive(params[p]);
-  const int K = g.K, nt = K + 1;
+  const int K = g.K, nt = K + 1, chunk = blockIdx.y;
+  const int k_lo = chunk * CHUNK, k_hi = min(K, k_lo + CHUNK) - 1;     // steps of this wavefront (node = step + 1)
   const unsigned oc = buf_off(t_, (int)SC(X_CUR));
-  const Scal s = load_scal(t_, sc, X_S);
-  tf_out[p] = s.th;
-  status_out[p] = (int)SC(X_STATUS);
-  iters_out[p] = rounds_instead_of_iters ? (int)SC(X_ROUNDS) : (int)SC(X_ITERS);
-  for (int k = 0; k < nt; k++) {
-    double z[7], u = 0.0, ax, ay;
-    if (k) {
-      const gdbl *sp = t_.st(k - 1);
-      ldo<7>(sp, Q_IT + O_Z, oc, z);
-      u = ROWO(sp, Q_IT + O_U, oc);
-      if (blob) {
-        const int kk = k - 1;
-        ASC_UNROLL
-        for (int i = 0; i < 7; i++) {
-          blob[(7L * kk + i) * batch + p] = z[i];
-          blob[(8L * K + 7L * kk + i) * batch + p] = ROWO(sp, Q_IT + O_L + i, oc);
-        }
-        blob[(7L * K + kk) * batch + p] = u;
-        ASC_UNROLL
-        for (int b = 0; b < 6; b++) blob[(15L * K + 6L * kk + b) * batch + p] = ROWO(sp, Q_IT + O_ZB + b, oc);
-      }
-    } else {
+  if (chunk == 0) {      // scalars, and node 0 (the fixed initial state)
+    const Scal s = load_scal(t_, sc, X_S);
+    tf_out[p] = s.th;
+    status_out[p] = (int)SC(X_STATUS);
+    iters_out[p] = rounds_instead_of_iters ? (int)SC(X_ROUNDS) : (int)SC(X_ITERS);
+    if (blob) {
+      double *bs = blob + (21L * K) * batch + p;
+      bs[S_TH * batch] = s.th; bs[S_ZLT * batch] = s.zlt; bs[S_ZUT * batch] = s.zut; bs[S_S1 * batch] = s.s1;
+      bs[S_S2 * batch] = s.s2; bs[S_ZS1 * batch] = s.zs1; bs[S_ZS2 * batch] = s.zs2; bs[S_NU3 * batch] = s.nu3;
+      bs[S_NU1 * batch] = s.nu1; bs[S_NU2 * batch] = s.nu2;
+    }
+    if (traj) {
+      double ax, ay;
+      accel<0>(d, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, ax, ay, nullptr, nullptr);
+      const double v[10] = {0.0, 0.0, 0.0, 0.0, ax, ay, 0.0, 0.0, 0.0, 0.0};
       ASC_UNROLL
-      for (int i = 0; i < 7; i++) z[i] = 0.0;
+      for (int f = 0; f < 10; f++) traj[((long)f * nt) * batch + p] = v[f];
+    }
+  }
+  for (int kk = k_lo; kk <= k_hi; kk++) {
+    const gdbl *sp = t_.st(kk);
+    double z[7], ax, ay;
+    ldo<7>(sp, Q_IT + O_Z, oc, z);
+    const double u = ROWO(sp, Q_IT + O_U, oc);
+    if (blob) {
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) {
+        blob[(7L * kk + i) * batch + p] = z[i];
+        blob[(8L * K + 7L * kk + i) * batch + p] = ROWO(sp, Q_IT + O_L + i, oc);
+      }
+      blob[(7L * K + kk) * batch + p] = u;
+      ASC_UNROLL
+      for (int b = 0; b < 6; b++) blob[(15L * K + 6L * kk + b) * batch + p] = ROWO(sp, Q_IT + O_ZB + b, oc);
     }
     if (traj) {
       accel<0>(d, z[IX], z[IY], z[IA], z[IM], 0.0, 0.0, ax, ay, nullptr, nullptr);
       const double v[10] = {z[IX], z[IY], z[IVX], z[IVY], ax, ay, z[IA], z[IW], u, z[IM]};
       ASC_UNROLL
-      for (int f = 0; f < 10; f++) traj[((long)f * nt + k) * batch + p] = v[f];
+      for (int f = 0; f < 10; f++) traj[((long)f * nt + kk + 1) * batch + p] = v[f];
     }
-  }
-  if (blob) {
-    double *bs = blob + (21L * K) * batch + p;
-    bs[S_TH * batch] = s.th; bs[S_ZLT * batch] = s.zlt; bs[S_ZUT * batch] = s.zut; bs[S_S1 * batch] = s.s1;
-    bs[S_S2 * batch] = s.s2; bs[S_ZS1 * batch] = s.zs1; bs[S_ZS2 * batch] = s.zs2; bs[S_NU3 * batch] = s.nu3;
-    bs[S_NU1 * batch] = s.nu1; bs[S_NU2 * batch] = s.nu2;
   }
 }
 
@@ -1525,7 +1530,7 @@ int pipeline_run(const ascent_params *dp, long batch, int K, int scheme, int for
   int host_cnt[3];
   const bool debug = getenv("ASCENT_DEBUG") != nullptr;
   int launches = 0;
-  hipLaunchKernelGGL(q_init, dim3(tiles), dim3(WAVE), 0, stream, dp, batch, g, ws, dguess, warm, mu0);
+  hipLaunchKernelGGL(q_init, dim3(tiles, g.nch), dim3(WAVE), 0, stream, dp, batch, g, ws, dguess, warm, mu0);
   PCHK(hipGetLastError());
   // Each round advances every lane by one stage of its own state machine: a lane in its normal flow
   // completes one interior-point iteration per round; a rejected line-search trial or a wrong-inertia
@@ -1572,7 +1577,7 @@ int pipeline_run(const ascent_params *dp, long batch, int K, int scheme, int for
     if (debug) fprintf(stderr, "[ascent pipeline] after round %ld: pending %d (refactor %d), stepping %d\n", round - 1, n_pending, host_cnt[2], n_factored);
     if (n_pending == 0 && n_factored == 0) break;
   }
-  hipLaunchKernelGGL(q_finish, dim3(tiles), dim3(WAVE), 0, stream, dp, batch, g, ws, dtraj, dtf, dstatus, diters,
+  hipLaunchKernelGGL(q_finish, dim3(tiles, g.nch), dim3(WAVE), 0, stream, dp, batch, g, ws, dtraj, dtf, dstatus, diters,
                      dblob, getenv("ASCENT_DEBUG_ROUNDS") != nullptr);
   PCHK(hipGetLastError());
   if (stats) stats->launches = launches + 2;
