@@ -214,8 +214,8 @@ def main():
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": ("split pipeline, 16-lane sweeps: q_trial_eval + q_factor_wide (decisions + factorisation; dominant) + q_forward_wide + "
-                           "q_local + q_adjoint_wide, one set per interior-point round" if B <= 8192 else
-                           "split pipeline, one-lane sweeps" if B <= 12288 else "k_solve (fused)"),
+                           "q_local + q_adjoint_wide, one set per interior-point round" if B <= 4096 else
+                           "split pipeline, one-lane sweeps" if B <= 24576 else "k_solve (fused)"),
                 "kernel_ms": k_ms, "algorithmic_bytes_per_launch": b_alg,
                 "fp64_achieved_tflops": f_alg / (k_ms * 1e-3) / 1e12,
                 "fp64_frac": f_alg / (k_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,

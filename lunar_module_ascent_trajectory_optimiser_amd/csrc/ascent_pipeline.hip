@@ -1540,7 +1540,7 @@ int pipeline_run(const ascent_params *dp, long batch, int K, int scheme, int for
   // for the host inside a burst.  A lane needs at most max_iter+1 accepted trial points plus a bounded number
   // of rejected trials and refactorisations per iteration, so the loop terminates.
   // the 16-lanes-per-NLP factorisation pays while the chip has idle SIMDs (see q_factor_wide)
-  bool wide = batch <= 8192;
+  bool wide = batch <= 4096;     // one wavefront per SIMD; beyond that the one-lane sweeps win (scripts/batch_sweep.py)
   if (const char *e = getenv("ASCENT_FACTOR")) wide = e[0] == 'w';
   int burst = 4;
   if (const char *e = getenv("ASCENT_ROUNDS_PER_SYNC")) { const int v = atoi(e); if (v >= 1 && v <= 64) burst = v; }

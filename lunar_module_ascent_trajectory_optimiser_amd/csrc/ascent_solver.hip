@@ -912,7 +912,7 @@ bool use_split_pipeline(int64_t batch) {
   const char *e = getenv("ASCENT_PIPELINE");
   if (e && !strcmp(e, "split")) return true;
   if (e && !strcmp(e, "fused")) return false;
-  return batch <= 12288;   // measured crossover on MI355X, N=200 (scripts/batch_sweep.py)
+  return batch <= 24576;   // measured crossover on MI355X, N=200 (scripts/batch_sweep.py)
 }
 
 // NLPs per wavefront (tile). 64 fills every lane; smaller values spread a small batch over more

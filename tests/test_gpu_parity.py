@@ -134,7 +134,7 @@ def test_split_and_fused_paths_agree(coracle, monkeypatch):
 
 def test_wide_and_one_lane_sweeps_agree(coracle, monkeypatch):
     """The split pipeline has two implementations of its three serial sweeps: one lane per NLP, and 16 lanes per
-    NLP (DPP row broadcasts + LDS transpose; used for batches <= 8192; ASCENT_FACTOR=lane|wide overrides).  Same
+    NLP (DPP row broadcasts + LDS transpose; used for batches <= 4096; ASCENT_FACTOR=lane|wide overrides).  Same
     algorithm, different summation order: identical iteration counts, answers equal to rounding, both equal to
     the oracle; ragged batch sizes exercise partially filled wavefronts and workgroups of the 16-lane kernels."""
     for scheme, form, P in ((0, "current", A.sweep_isp_drymass(10, 7)),
