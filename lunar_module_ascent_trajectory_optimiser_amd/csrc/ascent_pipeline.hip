@@ -1527,7 +1527,13 @@ int pipeline_run(const ascent_params *dp, long batch, int K, int scheme, int for
   Geo g{K, (K + CHUNK - 1) / CHUNK, form};
   const unsigned tiles = (unsigned)((batch + WAVE - 1) / WAVE);
   int *counters = (int *)((char *)ws + (size_t)tiles * g.tile_doubles() * sizeof(double));
-  int host_cnt[3];
+  // pinned mirror of the device counters (a copy into pageable memory stalls the stream for ~20 us per burst)
+  static int *host_cnt_dev[64] = {nullptr};      // per device: calls on one device are serialised by the caller's mutex
+  int dev_ = 0;
+  PCHK(hipGetDevice(&dev_));
+  dev_ &= 63;
+  if (!host_cnt_dev[dev_]) PCHK(hipHostMalloc((void **)&host_cnt_dev[dev_], 4 * sizeof(int)));
+  int *host_cnt = host_cnt_dev[dev_];
   const bool debug = getenv("ASCENT_DEBUG") != nullptr;
   int launches = 0;
   hipLaunchKernelGGL(q_init, dim3(tiles, g.nch), dim3(WAVE), 0, stream, dp, batch, g, ws, dguess, warm, mu0);
