@@ -180,7 +180,7 @@ def main():
         # iterations per grid level: `iters` counts both levels of the nested iteration; an untimed solve of the coarse
         # grid alone (the same first leg, deterministic) gives the split
         ntc = coarse_nodes_of(NT)
-        coarse = A.solve_batch_torch(P_t, ntc, tol=args.tol, want_traj=False, coarse_nodes=-1, sync=True)
+        coarse = A.solve_batch_torch(P_t, ntc, tol=max(args.tol, 1e-3), want_traj=False, coarse_nodes=-1, sync=True)   # the coarse leg's tolerance
         it_c = coarse["iters"].cpu().numpy()
         levels = [(NT, float((iters - it_c).sum())), (ntc, float(it_c.sum()))]
         b_alg = algorithmic_bytes(levels, len(iters), NT)

@@ -62,7 +62,8 @@ typedef struct ascent_opts {
   int32_t coarse_nodes; /* nested iteration for cold starts (warm_start == 0): the NLP is first solved on a coarse
                            grid, that primal-dual solution is prolonged to the n_nodes grid and warm-starts it.
                            0 = automatic (grids of >= 64 nodes; coarse grid = max(14, (n_nodes+5)/11) nodes,
-                           recursively), -1 = off (single grid), > 0 = that many coarse nodes (two levels).
+                           recursively; coarse levels are solved to max(tol, 1e-3)), -1 = off (single grid),
+                           > 0 = that many coarse nodes (two levels).
                            iters_out counts the iterations of all levels.                              */
 } ascent_opts;
 

@@ -842,6 +842,7 @@ int hip_fail(hipError_t e, const char *what) {
 // ---------------------------------------------------------------------------------------------
 constexpr int NESTED_MIN_NODES = 64;
 constexpr double NESTED_MU0 = 1e-5;
+constexpr double NESTED_COARSE_TOL = 1e-3;   // coarse levels: the reference's own OTOL/RTOL (their discretisation error is 1e-2)
 inline int coarse_of(int nt) { const int c = (nt + 5) / 11; return c < 14 ? 14 : c; }
 
 // Prolongation of external blobs ([row][batch]): linear in tau; node 0 is the fixed initial state (zero, except the
@@ -1099,15 +1100,16 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
     const double *g_l = first ? dguess : w.gss;
     const int warm_l = first ? (int)o->warm_start : 2;
     const double mu_l = first ? mu0 : NESTED_MU0;
+    const double tol_l = fin ? o->tol : fmax(o->tol, NESTED_COARSE_TOL);
     double *traj_l = fin ? dtraj : nullptr, *tf_l = fin ? dtf : w.tfc, *blob_l = fin ? dblob : w.sol;
     int *st_l = fin ? dstatus : w.st_c, *it_l = fin ? diters : w.it_c;
     if (split) {
-      rc = pipeline_run(dp, (long)batch, Kl, (int)o->scheme, (int)o->formulation, w.ws, g_l, warm_l, (int)o->max_iter, o->tol, mu_l,
+      rc = pipeline_run(dp, (long)batch, Kl, (int)o->scheme, (int)o->formulation, w.ws, g_l, warm_l, (int)o->max_iter, tol_l, mu_l,
                         traj_l, tf_l, st_l, it_l, blob_l, stream, nullptr, g_err, sizeof g_err);
       if (rc) return rc;
     } else {
       hipLaunchKernelGGL(k_solve, dim3(grid), dim3(WAVE), 0, stream, dp, (long)batch, lpt, Kl, w.ws, g_l, warm_l,
-                         (int)o->max_iter, o->tol, mu_l, traj_l, tf_l, st_l, it_l, blob_l);
+                         (int)o->max_iter, tol_l, mu_l, traj_l, tf_l, st_l, it_l, blob_l);
       HIPCHK(hipGetLastError());
     }
     if (!fin) {

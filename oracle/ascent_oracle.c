@@ -669,11 +669,12 @@ double oracle_kkt_error(const double *params, int nt, const double *blob, double
 /* ---- nested iteration (mesh continuation) ------------------------------------------------------------------
  * A cold start on a grid of >= 64 nodes first solves the same NLP on a grid of about a tenth of the nodes,
  * prolongs that primal-dual solution to the fine grid (linear in tau; node 0 is the fixed initial state; bound
- * multipliers scale with the step) and warm-starts the fine solve from it with mu0 = 1e-5.  Recursive in the
- * automatic mode.  A problem whose coarse solve does not converge starts cold on the fine grid. */
+ * multipliers scale with the step) and warm-starts the fine solve from it with mu0 = 1e-5.  The coarse levels are
+ * solved to max(tol, 1e-3) only: their discretisation error is 1e-2.  Recursive in the automatic mode.  A problem whose coarse solve does not converge starts cold on the fine grid. */
 static int coarse_of(int nt) { int c = (nt + 5) / 11; return c < 14 ? 14 : c; }
 #define NESTED_MIN_NODES 64
 #define NESTED_MU0 1e-5
+#define NESTED_COARSE_TOL 1e-3    /* the coarse levels are solved to the reference's own OTOL/RTOL, not to `tol` */
 
 static void prolong(const double *bc, int Kc, double *bf, int Kf) {
   iter_t c, f; view((double *)bc, Kc, &c); view(bf, Kf, &f);
@@ -705,7 +706,7 @@ static int solve_nested(const oparams *prm, int nt, int max_iter, double tol, in
     return solve_one(prm, nt, max_iter, tol, 0, 0.0, blob, iters_out, 0);
   double *bc = malloc(BLOB(nc - 1) * 8);
   int itc = 0, itf = 0;
-  const int stc = solve_nested(prm, nc, max_iter, tol, coarse > 0 ? -1 : 0, bc, &itc);
+  const int stc = solve_nested(prm, nc, max_iter, fmax(tol, NESTED_COARSE_TOL), coarse > 0 ? -1 : 0, bc, &itc);
   int warm = 0;
   if (stc == ST_CONVERGED) { prolong(bc, nc - 1, blob, nt - 1); warm = 2; }
   free(bc);
