@@ -76,6 +76,10 @@ def test_argument_validation(lib):
     o2 = _lib.AscentOptsC(n_nodes=200, scheme=7, max_iter=10, warm_start=0, tol=1e-8, mu_init=0.0)
     rc = lib.ascent_solve_batch(P.ctypes.data_as(C.c_void_p), 1, C.byref(o2), None, None, None, None, None, None, 0, None, 0)
     assert rc == -1 and b"scheme" in lib.ascent_strerror(rc)
+    for bad in (1, 2, 200, 500, -2):          # coarse grid of the nested iteration: -1, 0 or 3 .. n_nodes-1
+        o3 = _lib.AscentOptsC(n_nodes=200, scheme=0, max_iter=10, warm_start=0, tol=1e-8, mu_init=0.0, coarse_nodes=bad)
+        rc = lib.ascent_solve_batch(P.ctypes.data_as(C.c_void_p), 1, C.byref(o3), None, None, None, None, None, None, 0, None, 0)
+        assert rc == -1 and b"coarse_nodes" in lib.ascent_strerror(rc)
 
 
 def test_product_does_not_import_oracle():
