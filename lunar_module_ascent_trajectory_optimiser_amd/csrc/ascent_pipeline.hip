@@ -207,7 +207,8 @@ ASC_DEV unsigned buf_off(const QTile &t_, int buf) { return t_.lane + (unsigned)
 // lambda_k + lambda_{k+1} with step constant cs = dt/2, and the stored step function is the mean of the two f's.
 template <int SCHEME, int FORM>
 __global__ __launch_bounds__(WAVE) void q_trial_eval(const ascent_params *params, long batch, Geo g,
-                                                     double *ws) {
+                                                     double *ws, int *counters) {
+  if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x < 3) counters[threadIdx.x] = 0;   // the round's counters
   const long p = (long)blockIdx.x * WAVE + threadIdx.x;
   if (p >= batch) return;
   const QTile t_((gdbl *)ws + (size_t)blockIdx.x * g.tile_doubles());
@@ -1559,8 +1560,7 @@ int pipeline_run(const ascent_params *dp, long batch, int K, int scheme, int for
   for (long round = 0;;) {
     if (round > 100L * (max_iter + 2)) { snprintf(err, errlen, "pipeline did not terminate"); return ASCENT_E_HIP; }
     for (int r = 0; r < burst; r++, round++) {
-      ASC_LAUNCH(q_trial_eval, dim3(tiles, g.nch), dp, batch, g, ws);
-      PCHK(hipMemsetAsync(counters, 0, 3 * sizeof(int), stream));
+      ASC_LAUNCH(q_trial_eval, dim3(tiles, g.nch), dp, batch, g, ws, counters);
       if (!wide) ASC_LAUNCH(q_decide_factor, dim3(tiles), dp, batch, g, ws, max_iter, tol, counters);
       const dim3 wgrid((unsigned)((batch + WIDE_NLP_PER_BLOCK - 1) / WIDE_NLP_PER_BLOCK));
 #define ASC_LAUNCH_WIDE(KERNEL, ...)                                                                                \
