@@ -47,7 +47,7 @@ typedef struct ascent_params {
 } ascent_params;
 
 typedef struct ascent_opts {
-  int32_t n_nodes;     /* :20  nt, number of grid points (tau_k = k/(nt-1), :21)         */
+  int32_t n_nodes;     /* :20  nt, number of grid points (tau_k = k/(nt-1), :21), 3 .. 65536 */
   int32_t scheme;      /* 0 = NODES=2 two-point collocation = backward Euler (:25);
                           1 = trapezoid, control held over the step (not a reference scheme) */
   int32_t max_iter;    /* :28  interior-point iteration cap                              */
@@ -72,7 +72,9 @@ enum ascent_status {           /* function return codes */
   ASCENT_E_ARG = -1,           /* null pointer / bad size / unsupported option           */
   ASCENT_E_HIP = -2,           /* a HIP runtime call failed (see ascent_strerror)        */
   ASCENT_E_NODEVICE = -3,      /* no such device                                         */
-  ASCENT_E_NOMEM = -4          /* workspace allocation failed                            */
+  ASCENT_E_NOMEM = -4,         /* workspace allocation failed                            */
+  ASCENT_E_NOTERM = -5         /* the host-steered pipeline exceeded its round budget (a solver
+                                  condition that the per-problem statuses could not express)   */
 };
 
 enum ascent_problem_status {   /* values written to status_out[] */
@@ -108,9 +110,14 @@ const char *ascent_strerror(int code);
  * traj_out [10*n_nodes][batch], tf_out/status_out/iters_out [batch]; sol_blob_out_or_null
  * [21K+10][batch] receives the full primal-dual solution (usable as a warm start).
  * stream: hipStream_t or NULL.  With host pointers the call returns after the results are in the
- * caller's buffers.  With ptr_is_device != 0 and a stream, large batches (fused kernel) are only
- * enqueued; small batches (split pipeline, <= 12 288 NLPs or scheme 1) synchronise the stream once
- * per interior-point round, because the host steers the rounds, and return with all kernels enqueued. */
+ * caller's buffers.  With ptr_is_device != 0 and a stream, large batches (fused kernel, > 24 576 NLPs,
+ * scheme 0 / formulation 0) are only enqueued; smaller batches (split pipeline; also every scheme-1 or
+ * formulation-1 batch) synchronise the stream once per burst of four interior-point rounds, because the
+ * host steers the rounds, and return with the last kernels enqueued.
+ * Concurrency: the library keeps ONE workspace per device.  Calls on the same device are serialised on the
+ * host by a mutex, and a call whose predecessor on that device is still executing (asynchronous device-
+ * pointer calls on different streams) makes its stream wait for the predecessor's last kernel first
+ * (hipStreamWaitEvent), so two solves never share the workspace in flight. */
 int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts *o,
                        const double *guess_or_null, double *traj_out, double *tf_out,
                        int32_t *status_out, int32_t *iters_out, double *sol_blob_out_or_null,
@@ -134,6 +141,22 @@ int ascent_eval_nodes(const ascent_params *p, int64_t batch, const ascent_opts *
 int ascent_kkt_step(const ascent_params *p, int64_t batch, const ascent_opts *o,
                     const double *iterate, const double *mu, const double *delta_w, double *step,
                     int32_t *inertia_out, int device_id);
+
+/* The same two parity surfaces through a chosen solver path.  ascent_eval_nodes / ascent_kkt_step above take the path
+ * ascent_solve_batch would take for that batch (batch-size rule, ASCENT_PIPELINE / ASCENT_FACTOR environment
+ * overrides); these run one round of exactly the kernels of the named path at the given iterate:
+ *   ASCENT_PATH_FUSED       k_eval_nodes / the passes of k_solve (scheme 0, formulation 0 only)
+ *   ASCENT_PATH_SPLIT_LANE  q_trial_eval -> q_decide_factor -> q_forward -> q_local -> q_adjoint
+ *   ASCENT_PATH_SPLIT_WIDE  q_trial_eval -> q_factor_wide -> q_forward_wide -> q_local -> q_adjoint_wide
+ * The split paths take schemes 0/1 and formulations 0/1.  For scheme 1 (trapezoid) `defects` is the trapezoid
+ * defect and the Hessian block of node k is weighted by -(h*T*tf/2)*(lambda_k + lambda_{k+1}). */
+enum ascent_path { ASCENT_PATH_AUTO = 0, ASCENT_PATH_FUSED = 1, ASCENT_PATH_SPLIT_LANE = 2, ASCENT_PATH_SPLIT_WIDE = 3 };
+int ascent_eval_nodes_path(const ascent_params *p, int64_t batch, const ascent_opts *o,
+                           const double *iterate, double *defects, double *jac_blocks,
+                           double *hess_blocks, int device_id, int path);
+int ascent_kkt_step_path(const ascent_params *p, int64_t batch, const ascent_opts *o,
+                         const double *iterate, const double *mu, const double *delta_w, double *step,
+                         int32_t *inertia_out, int device_id, int path);
 
 /* Device time (ms) of the solve kernel of the most recent ascent_solve_batch on this device,
  * measured with HIP events recorded on the launch stream around the kernel; waits for that

@@ -30,7 +30,9 @@ class AscentOptsC(C.Structure):
 
 
 SYMBOLS = ("ascent_version", "ascent_device_count", "ascent_strerror", "ascent_solve_batch",
-           "ascent_eval_nodes", "ascent_kkt_step", "ascent_last_kernel_ms")
+           "ascent_eval_nodes", "ascent_kkt_step", "ascent_eval_nodes_path", "ascent_kkt_step_path",
+           "ascent_last_kernel_ms")
+PATHS = {"auto": 0, "fused": 1, "split_lane": 2, "split_wide": 3}     # enum ascent_path
 
 _lib = None
 
@@ -67,6 +69,10 @@ def load():
     L.ascent_kkt_step.restype = C.c_int
     L.ascent_kkt_step.argtypes = [C.c_void_p, C.c_int64, C.POINTER(AscentOptsC), C.c_void_p, C.c_void_p,
                                   C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
+    L.ascent_eval_nodes_path.restype = C.c_int
+    L.ascent_eval_nodes_path.argtypes = L.ascent_eval_nodes.argtypes + [C.c_int]
+    L.ascent_kkt_step_path.restype = C.c_int
+    L.ascent_kkt_step_path.argtypes = L.ascent_kkt_step.argtypes + [C.c_int]
     _lib = L
     return L
 

@@ -60,6 +60,8 @@ using QTile = TileT<Q_STAGE>;
 
 struct Geo {      // geometry of the workspace (+ formulation: 0 current script, 1 v1 script)
   int K, nch, form;
+  int probe;      // parity probe (pipeline_probe): one Newton step at the caller's iterate with the caller's mu and delta_w --
+                  // the iterate is taken as it is, no convergence test, no barrier update, no refactorisation
   __host__ __device__ size_t tile_doubles() const {
     return ((size_t)K * Q_STAGE + NSCAL + (size_t)nch * NPART) * WAVE;
   }
@@ -102,7 +104,8 @@ ASC_DEV Scal trial_scal(const Der &d, const Scal &s, const Scal &ds, double alph
 // (grid tiles x chunks); the wavefront of the last chunk also sets the scalars.
 // ==============================================================================================
 __global__ __launch_bounds__(WAVE) void q_init(const ascent_params *params, long batch, Geo g, double *ws,
-                                               const double *guess, int warm, double mu_init) {
+                                               const double *guess, int warm, double mu_init,
+                                               const double *probe_mu, const double *probe_dw) {
   const long p = (long)blockIdx.x * WAVE + threadIdx.x;
   if (p >= batch) return;
   const QTile t_((gdbl *)ws + (size_t)blockIdx.x * g.tile_doubles());
@@ -139,11 +142,13 @@ __global__ __launch_bounds__(WAVE) void q_init(const ascent_params *params, long
         u = z[IA] / (0.5 * d.aub) - 1.0;
       }
     }
-    z[IA] = push_in(z[IA], 0.0, d.aub);
-    z[IM] = push_in(z[IM], 0.0, 1.0);
-    u = push_in(u, -1.0, 1.0);
+    if (!g.probe) {
+      z[IA] = push_in(z[IA], 0.0, d.aub);
+      z[IM] = push_in(z[IM], 0.0, 1.0);
+      u = push_in(u, -1.0, 1.0);
+    }
     ASC_UNROLL
-    for (int b = 0; b < 6; b++) zb[b] = warm == 2 ? fmax(zb[b], 1e-12) : 1.0;
+    for (int b = 0; b < 6; b++) zb[b] = warm == 2 ? (g.probe ? zb[b] : fmax(zb[b], 1e-12)) : 1.0;
     ASC_UNROLL
     for (int i = 0; i < 7; i++) l[i] = warm == 2 ? l[i] : 0.0;
     stn<7>(t_, sp, Q_IT + O_Z, z);
@@ -166,9 +171,11 @@ __global__ __launch_bounds__(WAVE) void q_init(const ascent_params *params, long
   } else {
     s.th = tf0;
   }
-  s.th = push_in(s.th, d.tlb, d.tub);
+  if (!g.probe) s.th = push_in(s.th, d.tlb, d.tub);
   const Terminal tm = terminal_eval(d, zK);
-  if (warm != 2) {
+  if (g.probe) {
+    // the caller's iterate as it is
+  } else if (warm != 2) {
     s.s1 = fmax(tm.g1, 1e-2); s.s2 = fmax(tm.g2, 1e-2);
     s.zlt = s.zut = s.zs1 = s.zs2 = 1.0;
     s.nu3 = s.nu1 = s.nu2 = 0.0;
@@ -181,6 +188,7 @@ __global__ __launch_bounds__(WAVE) void q_init(const ascent_params *params, long
   store_scal(t_, sc, X_S, s);
   SC(X_STATE) = ST_TRIAL; SC(X_FIRST) = 1.0; SC(X_STATUS) = ASCENT_MAX_ITER;
   SC(X_MU) = (asked_warm && !warm) ? 0.1 : mu_init; SC(X_NUP) = 1.0;
+  if (g.probe) { SC(X_MU) = probe_mu[p]; SC(X_DW) = probe_dw[p]; }
 }
 
 // per-lane iterate buffer: lanes advance asynchronously, so which of the two iterate buffers holds a
@@ -524,6 +532,11 @@ ASC_DEV Decided decide_lane(const QTile &t_, gdbl *sc, const Geo &g, const Der &
   l1 += fabs(st.nu3) + fabs(st.nu1) + fabs(st.nu2);
   zsum += st.zlt + st.zut + st.zs1 + st.zs2;
   e.sd = fmax(100.0, (l1 + zsum) / (double)(13 * K + 7)) * 0.01;
+  if (g.probe) {         // parity probe: factorise here and now with the caller's mu and delta_w
+    out.dw = SC(X_DW);
+    out.state = ST_FACTOR;
+    return out;
+  }
   if (e.err(0.0) <= tol) {
     WSC(X_STATUS, ASCENT_CONVERGED); WSC(X_STATE, ST_DONE);
     out.state = ST_DONE;
@@ -1498,6 +1511,56 @@ __global__ __launch_bounds__(WAVE) void q_finish(const ascent_params *params, lo
   }
 }
 
+
+// ==============================================================================================
+// q_probe_out: what one round of the pipeline left behind, in the external layouts (parity surfaces
+// ascent_kkt_step / ascent_eval_nodes of include/ascent.h).  One wavefront = 64 NLPs x CHUNK steps.
+// ==============================================================================================
+__global__ __launch_bounds__(WAVE) void q_probe_out(const ascent_params *params, long batch, Geo g, double *ws,
+                                                    double *step, int *inertia, double *defects, double *jac,
+                                                    double *hess) {
+  const long p = (long)blockIdx.x * WAVE + threadIdx.x;
+  if (p >= batch) return;
+  const QTile t_((gdbl *)ws + (size_t)blockIdx.x * g.tile_doubles());
+  gdbl *sc = scal_base(t_, g);
+  const Der d = derive(params[p]);
+  const int K = g.K, chunk = blockIdx.y;
+  const int k_lo = chunk * CHUNK, k_hi = min(K, k_lo + CHUNK) - 1;
+  const unsigned oc = buf_off(t_, (int)SC(X_CUR));
+  if (chunk == 0) {
+    if (inertia) inertia[p] = (int)SC(X_STATE) == ST_FACTOR ? 1 : 0;     // a lane whose factorisation was refused is still waiting for one
+    if (step)
+      for (int r = 0; r < NSC; r++) step[(21L * K + r) * batch + p] = SC(X_D + r);
+  }
+  for (int k = k_lo; k <= k_hi; k++) {
+    const gdbl *sp = t_.st(k);
+    if (step) {
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) {
+        step[(7L * k + i) * batch + p] = ROW(sp, Q_ST + O_Z + i);
+        step[(8L * K + 7L * k + i) * batch + p] = ROW(sp, Q_ST + O_L + i);
+      }
+      step[(7L * K + k) * batch + p] = ROW(sp, Q_ST + O_U);
+      ASC_UNROLL
+      for (int b = 0; b < 6; b++) step[(15L * K + 6L * k + b) * batch + p] = ROW(sp, Q_ST + O_ZB + b);
+    }
+    if (defects) {
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) defects[(7L * k + i) * batch + p] = ROW(sp, Q_C + i);
+      ASC_UNROLL
+      for (int i = 0; i < 8; i++) jac[(8L * k + i) * batch + p] = ROW(sp, Q_G + i);
+      // the stored Hessian block carries the bound-barrier curvature of angle and mass (see q_trial_eval): take it out again
+      const double a = ROWO(sp, Q_IT + O_Z + IA, oc), m = ROWO(sp, Q_IT + O_Z + IM, oc);
+      double zb[4];
+      ldo<4>(sp, Q_IT + O_ZB, oc, zb);
+      const double sa = zb[0] * rcp(a) + zb[1] * rcp(d.aub - a), sm = zb[2] * rcp(m) + zb[3] * rcp(1.0 - m);
+      ASC_UNROLL
+      for (int i = 0; i < 10; i++)
+        hess[(10L * k + i) * batch + p] = ROW(sp, Q_H + i) - (i == 7 ? sa : i == 9 ? sm : 0.0);
+    }
+  }
+}
+
 }  // namespace
 
 // ==============================================================================================
@@ -1515,17 +1578,29 @@ extern "C" int ascent_debug_df_stamps(unsigned long long *out6, int reset) {
 namespace ascent {
 
 size_t pipeline_ws_bytes(int K, long batch) {
-  Geo g{K, (K + CHUNK - 1) / CHUNK, 0};
+  Geo g{K, (K + CHUNK - 1) / CHUNK, 0, 0};
   const size_t tiles = (size_t)((batch + WAVE - 1) / WAVE);
   return tiles * g.tile_doubles() * sizeof(double) + 64;   // + counters
 }
 
+#define ASC_LAUNCH(KERNEL, GRID, ...)                                                                               \
+  do {                                                                                                              \
+    if (form == 1) hipLaunchKernelGGL((KERNEL<0, 1>), GRID, dim3(WAVE), 0, stream, __VA_ARGS__);                    \
+    else if (scheme == 1) hipLaunchKernelGGL((KERNEL<1, 0>), GRID, dim3(WAVE), 0, stream, __VA_ARGS__);            \
+    else hipLaunchKernelGGL((KERNEL<0, 0>), GRID, dim3(WAVE), 0, stream, __VA_ARGS__);                              \
+  } while (0)
+#define ASC_LAUNCH_WIDE(KERNEL, ...)                                                                                \
+  do {                                                                                                              \
+    if (form == 1) hipLaunchKernelGGL((KERNEL<0, 1>), wgrid, dim3(WIDE_THREADS), 0, stream, __VA_ARGS__);           \
+    else if (scheme == 1) hipLaunchKernelGGL((KERNEL<1, 0>), wgrid, dim3(WIDE_THREADS), 0, stream, __VA_ARGS__);   \
+    else hipLaunchKernelGGL((KERNEL<0, 0>), wgrid, dim3(WIDE_THREADS), 0, stream, __VA_ARGS__);                     \
+  } while (0)
 #define PCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf(err, errlen, "%s: %s", #call, hipGetErrorString(e_)); return ASCENT_E_HIP; } } while (0)
 
 int pipeline_run(const ascent_params *dp, long batch, int K, int scheme, int form, double *ws, const double *dguess, int warm,
                  int max_iter, double tol, double mu0, double *dtraj, double *dtf, int *dstatus, int *diters,
                  double *dblob, hipStream_t stream, PipelineStats *stats, char *err, size_t errlen) {
-  Geo g{K, (K + CHUNK - 1) / CHUNK, form};
+  Geo g{K, (K + CHUNK - 1) / CHUNK, form, 0};
   const unsigned tiles = (unsigned)((batch + WAVE - 1) / WAVE);
   int *counters = (int *)((char *)ws + (size_t)tiles * g.tile_doubles() * sizeof(double));
   // pinned mirror of the device counters (a copy into pageable memory stalls the stream for ~20 us per burst)
@@ -1537,7 +1612,8 @@ int pipeline_run(const ascent_params *dp, long batch, int K, int scheme, int for
   int *host_cnt = host_cnt_dev[dev_];
   const bool debug = getenv("ASCENT_DEBUG") != nullptr;
   int launches = 0;
-  hipLaunchKernelGGL(q_init, dim3(tiles, g.nch), dim3(WAVE), 0, stream, dp, batch, g, ws, dguess, warm, mu0);
+  hipLaunchKernelGGL(q_init, dim3(tiles, g.nch), dim3(WAVE), 0, stream, dp, batch, g, ws, dguess, warm, mu0,
+                     (const double *)nullptr, (const double *)nullptr);
   PCHK(hipGetLastError());
   // Each round advances every lane by one stage of its own state machine: a lane in its normal flow
   // completes one interior-point iteration per round; a rejected line-search trial or a wrong-inertia
@@ -1551,24 +1627,12 @@ int pipeline_run(const ascent_params *dp, long batch, int K, int scheme, int for
   if (const char *e = getenv("ASCENT_FACTOR")) wide = e[0] == 'w';
   int burst = 4;
   if (const char *e = getenv("ASCENT_ROUNDS_PER_SYNC")) { const int v = atoi(e); if (v >= 1 && v <= 64) burst = v; }
-#define ASC_LAUNCH(KERNEL, GRID, ...)                                                                               \
-  do {                                                                                                              \
-    if (form == 1) hipLaunchKernelGGL((KERNEL<0, 1>), GRID, dim3(WAVE), 0, stream, __VA_ARGS__);                    \
-    else if (scheme == 1) hipLaunchKernelGGL((KERNEL<1, 0>), GRID, dim3(WAVE), 0, stream, __VA_ARGS__);            \
-    else hipLaunchKernelGGL((KERNEL<0, 0>), GRID, dim3(WAVE), 0, stream, __VA_ARGS__);                              \
-  } while (0)
   for (long round = 0;;) {
-    if (round > 100L * (max_iter + 2)) { snprintf(err, errlen, "pipeline did not terminate"); return ASCENT_E_HIP; }
+    if (round > 100L * (max_iter + 2)) { snprintf(err, errlen, "pipeline did not terminate within %ld rounds (solver condition, not a HIP error)", round); return ASCENT_E_NOTERM; }
     for (int r = 0; r < burst; r++, round++) {
       ASC_LAUNCH(q_trial_eval, dim3(tiles, g.nch), dp, batch, g, ws, counters);
       if (!wide) ASC_LAUNCH(q_decide_factor, dim3(tiles), dp, batch, g, ws, max_iter, tol, counters);
       const dim3 wgrid((unsigned)((batch + WIDE_NLP_PER_BLOCK - 1) / WIDE_NLP_PER_BLOCK));
-#define ASC_LAUNCH_WIDE(KERNEL, ...)                                                                                \
-  do {                                                                                                              \
-    if (form == 1) hipLaunchKernelGGL((KERNEL<0, 1>), wgrid, dim3(WIDE_THREADS), 0, stream, __VA_ARGS__);           \
-    else if (scheme == 1) hipLaunchKernelGGL((KERNEL<1, 0>), wgrid, dim3(WIDE_THREADS), 0, stream, __VA_ARGS__);   \
-    else hipLaunchKernelGGL((KERNEL<0, 0>), wgrid, dim3(WIDE_THREADS), 0, stream, __VA_ARGS__);                     \
-  } while (0)
       if (wide) ASC_LAUNCH_WIDE(q_factor_wide, dp, batch, g, ws, max_iter, tol, counters);
       if (r == burst - 1) PCHK(hipMemcpyAsync(host_cnt, counters, 3 * sizeof(int), hipMemcpyDeviceToHost, stream));
       if (!wide) ASC_LAUNCH(q_forward, dim3(tiles), dp, batch, g, ws);
@@ -1577,6 +1641,7 @@ int pipeline_run(const ascent_params *dp, long batch, int K, int scheme, int for
       if (!wide) ASC_LAUNCH(q_adjoint, dim3(tiles), dp, batch, g, ws);
       else ASC_LAUNCH_WIDE(q_adjoint_wide, dp, batch, g, ws);
       launches += 5;
+      PCHK(hipGetLastError());      // a refused launch must not hide behind the rest of the burst
     }
     PCHK(hipStreamSynchronize(stream));
     const int n_pending = host_cnt[0], n_factored = host_cnt[1];   // retrial/refactor lanes; lanes with a step to take
@@ -1587,6 +1652,41 @@ int pipeline_run(const ascent_params *dp, long batch, int K, int scheme, int for
                      dblob, getenv("ASCENT_DEBUG_ROUNDS") != nullptr);
   PCHK(hipGetLastError());
   if (stats) stats->launches = launches + 2;
+  return ASCENT_OK;
+}
+
+
+// One round of the pipeline at a caller-supplied iterate (parity surface): q_init takes the iterate as it is, then exactly
+// the kernels a solve launches per round -- q_trial_eval, the factorisation (one-lane or 16-lane), forward, q_local,
+// adjoint -- with mu and delta_w per problem from the caller; q_probe_out hands back the Newton step and/or the node rows.
+int pipeline_probe(const ascent_params *dp, long batch, int K, int scheme, int form, double *ws, const double *diterate,
+                   const double *dmu, const double *ddw, bool wide, bool step_too, double *dstep, int *dinertia,
+                   double *ddefects, double *djac, double *dhess, hipStream_t stream, char *err, size_t errlen) {
+  Geo g{K, (K + CHUNK - 1) / CHUNK, form, 1};
+  const unsigned tiles = (unsigned)((batch + WAVE - 1) / WAVE);
+  int *counters = (int *)((char *)ws + (size_t)tiles * g.tile_doubles() * sizeof(double));
+  hipLaunchKernelGGL(q_init, dim3(tiles, g.nch), dim3(WAVE), 0, stream, dp, batch, g, ws, diterate, 2, 0.1, dmu, ddw);
+  PCHK(hipGetLastError());
+  ASC_LAUNCH(q_trial_eval, dim3(tiles, g.nch), dp, batch, g, ws, counters);
+  PCHK(hipGetLastError());
+  if (step_too) {
+    const dim3 wgrid((unsigned)((batch + WIDE_NLP_PER_BLOCK - 1) / WIDE_NLP_PER_BLOCK));
+    if (wide) {
+      ASC_LAUNCH_WIDE(q_factor_wide, dp, batch, g, ws, 1 << 30, -1.0, counters);
+      ASC_LAUNCH_WIDE(q_forward_wide, dp, batch, g, ws);
+    } else {
+      ASC_LAUNCH(q_decide_factor, dim3(tiles), dp, batch, g, ws, 1 << 30, -1.0, counters);
+      ASC_LAUNCH(q_forward, dim3(tiles), dp, batch, g, ws);
+    }
+    PCHK(hipGetLastError());
+    hipLaunchKernelGGL(q_local, dim3(tiles, g.nch), dim3(WAVE), 0, stream, dp, batch, g, ws);
+    if (wide) ASC_LAUNCH_WIDE(q_adjoint_wide, dp, batch, g, ws);
+    else ASC_LAUNCH(q_adjoint, dim3(tiles), dp, batch, g, ws);
+    PCHK(hipGetLastError());
+  }
+  hipLaunchKernelGGL(q_probe_out, dim3(tiles, g.nch), dim3(WAVE), 0, stream, dp, batch, g, ws, step_too ? dstep : nullptr,
+                     step_too ? dinertia : nullptr, ddefects, djac, dhess);
+  PCHK(hipGetLastError());
   return ASCENT_OK;
 }
 

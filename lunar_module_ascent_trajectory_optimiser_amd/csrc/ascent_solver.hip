@@ -900,6 +900,11 @@ struct DeviceWs {
   double *sol = nullptr, *gss = nullptr, *tfc = nullptr;
   size_t sol_n = 0, gss_n = 0, int_n = 0;
   int *st_c = nullptr, *it_c = nullptr, *acc = nullptr;
+  // staging buffers of host-pointer calls, kept between calls (the GEKKO-style front end solves one NLP per call)
+  ascent_params *h_p = nullptr;
+  double *h_guess = nullptr, *h_traj = nullptr, *h_tf = nullptr, *h_blob = nullptr;
+  int *h_status = nullptr, *h_iters = nullptr;
+  size_t h_p_n = 0, h_guess_n = 0, h_traj_n = 0, h_tf_n = 0, h_blob_n = 0, h_status_n = 0, h_iters_n = 0;
 };
 constexpr int MAX_DEV = 64;
 DeviceWs g_ws[MAX_DEV];
@@ -962,7 +967,7 @@ int grow(T *&ptr, size_t &have, size_t need) {
 
 int check_common(const ascent_params *p, int64_t batch, const ascent_opts *o, int device_id) {
   if (!p || !o || batch <= 0) { snprintf(g_err, sizeof g_err, "null params/opts or batch <= 0"); return ASCENT_E_ARG; }
-  if (o->n_nodes < 3 || o->n_nodes > 100000) { snprintf(g_err, sizeof g_err, "n_nodes out of range"); return ASCENT_E_ARG; }
+  if (o->n_nodes < 3 || o->n_nodes > 65536) { snprintf(g_err, sizeof g_err, "n_nodes out of range (3 .. 65536)"); return ASCENT_E_ARG; }
   if (o->formulation != 0 && o->formulation != 1) { snprintf(g_err, sizeof g_err, "formulation %d not supported (0 = current script, 1 = v1 script)", o->formulation); return ASCENT_E_ARG; }
   if (o->formulation == 1 && o->scheme != 0) { snprintf(g_err, sizeof g_err, "formulation 1 is available with scheme 0 only"); return ASCENT_E_ARG; }
   if (o->coarse_nodes != -1 && o->coarse_nodes != 0 && (o->coarse_nodes < 3 || o->coarse_nodes >= o->n_nodes)) { snprintf(g_err, sizeof g_err, "coarse_nodes must be -1 (off), 0 (automatic) or in [3, n_nodes)"); return ASCENT_E_ARG; }
@@ -993,7 +998,7 @@ int ascent_debug_profile(unsigned long long *out8, int reset) {
 }
 #endif
 
-int ascent_version(void) { return 103; }
+int ascent_version(void) { return 200; }
 
 int ascent_device_count(void) {
   int n = 0;
@@ -1004,7 +1009,7 @@ int ascent_device_count(void) {
 const char *ascent_strerror(int code) {
   switch (code) {
     case ASCENT_OK: return "ok";
-    case ASCENT_E_ARG: case ASCENT_E_HIP: case ASCENT_E_NODEVICE: case ASCENT_E_NOMEM:
+    case ASCENT_E_ARG: case ASCENT_E_HIP: case ASCENT_E_NODEVICE: case ASCENT_E_NOMEM: case ASCENT_E_NOTERM:
       return g_err[0] ? g_err : "error";
     default: return "unknown error code";
   }
@@ -1048,23 +1053,25 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
   const double *dguess = guess;
   double *dtraj = traj_out, *dtf = tf_out, *dblob = sol_blob_out;
   int *dstatus = status_out, *diters = iters_out;
-  DevBuf<ascent_params> bp;
-  DevBuf<double> bguess, btraj, btf, bblob;
-  DevBuf<int> bstatus, biters;
+  // a predecessor on this device may still be executing on another stream: it owns the workspace until its last kernel
+  if (w.launched) HIPCHK(hipStreamWaitEvent(stream, w.ev1, 0));
   if (!ptr_is_device) {
-    HIPCHK(bp.alloc(batch));
-    HIPCHK(hipMemcpyAsync(bp.d, p, batch * sizeof(ascent_params), hipMemcpyHostToDevice, stream));
-    dp = bp.d;
+    if ((rc = grow(w.h_p, w.h_p_n, (size_t)batch))) return rc;
+    HIPCHK(hipMemcpyAsync(w.h_p, p, batch * sizeof(ascent_params), hipMemcpyHostToDevice, stream));
+    dp = w.h_p;
     if (o->warm_start) {
-      HIPCHK(bguess.alloc(rows * batch));
-      HIPCHK(hipMemcpyAsync(bguess.d, guess, rows * batch * sizeof(double), hipMemcpyHostToDevice, stream));
-      dguess = bguess.d;
+      if ((rc = grow(w.h_guess, w.h_guess_n, rows * batch))) return rc;
+      HIPCHK(hipMemcpyAsync(w.h_guess, guess, rows * batch * sizeof(double), hipMemcpyHostToDevice, stream));
+      dguess = w.h_guess;
     }
-    if (traj_out) { HIPCHK(btraj.alloc((size_t)10 * nt * batch)); dtraj = btraj.d; }
-    if (sol_blob_out) { HIPCHK(bblob.alloc(rows * batch)); dblob = bblob.d; }
-    HIPCHK(btf.alloc(batch)); dtf = btf.d;
-    HIPCHK(bstatus.alloc(batch)); dstatus = bstatus.d;
-    HIPCHK(biters.alloc(batch)); diters = biters.d;
+    if (traj_out) { if ((rc = grow(w.h_traj, w.h_traj_n, (size_t)10 * nt * batch))) return rc; dtraj = w.h_traj; }
+    if (sol_blob_out) { if ((rc = grow(w.h_blob, w.h_blob_n, rows * batch))) return rc; dblob = w.h_blob; }
+    if ((rc = grow(w.h_tf, w.h_tf_n, (size_t)batch))) return rc;
+    dtf = w.h_tf;
+    if ((rc = grow(w.h_status, w.h_status_n, (size_t)batch))) return rc;
+    dstatus = w.h_status;
+    if ((rc = grow(w.h_iters, w.h_iters_n, (size_t)batch))) return rc;
+    diters = w.h_iters;
   }
   const unsigned grid = (unsigned)((batch + lpt - 1) / lpt);
   // grid levels of the nested iteration, finest first (levels[0] = n_nodes); one level = a plain solve
@@ -1136,43 +1143,75 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
   return ASCENT_OK;
 }
 
-int ascent_eval_nodes(const ascent_params *p, int64_t batch, const ascent_opts *o, const double *iterate,
-                      double *defects, double *jac_blocks, double *hess_blocks, int device_id) {
+// which kernels a parity-surface call runs: an explicit path, or (AUTO) the one ascent_solve_batch would take
+static int resolve_path(int path, const ascent_opts *o, int64_t batch) {
+  if (path == ASCENT_PATH_AUTO) {
+    const bool split = o->scheme == 1 || o->formulation == 1 || use_split_pipeline(batch);
+    if (!split) return ASCENT_PATH_FUSED;
+    bool wide = batch <= 4096;
+    if (const char *e = getenv("ASCENT_FACTOR")) wide = e[0] == 'w';
+    return wide ? ASCENT_PATH_SPLIT_WIDE : ASCENT_PATH_SPLIT_LANE;
+  }
+  return path;
+}
+
+int ascent_eval_nodes_path(const ascent_params *p, int64_t batch, const ascent_opts *o, const double *iterate,
+                           double *defects, double *jac_blocks, double *hess_blocks, int device_id, int path) {
   int rc = check_common(p, batch, o, device_id);
   if (rc) return rc;
   if (!iterate || !defects || !jac_blocks || !hess_blocks) { snprintf(g_err, sizeof g_err, "null pointer"); return ASCENT_E_ARG; }
-  if (o->scheme != 0 || o->formulation != 0) { snprintf(g_err, sizeof g_err, "ascent_eval_nodes: scheme 0, formulation 0 only"); return ASCENT_E_ARG; }
+  if (path < ASCENT_PATH_AUTO || path > ASCENT_PATH_SPLIT_WIDE) { snprintf(g_err, sizeof g_err, "unknown path %d", path); return ASCENT_E_ARG; }
+  path = resolve_path(path, o, batch);
+  if (path == ASCENT_PATH_FUSED && (o->scheme != 0 || o->formulation != 0)) { snprintf(g_err, sizeof g_err, "the fused path has scheme 0, formulation 0 only"); return ASCENT_E_ARG; }
   std::lock_guard<std::mutex> lock(g_mu[device_id]);
   HIPCHK(hipSetDevice(device_id));
   const int K = o->n_nodes - 1;
   const size_t rows = 21 * (size_t)K + NSC;
   DevBuf<ascent_params> bp;
-  DevBuf<double> bit, bd, bj, bh;
+  DevBuf<double> bit, bd, bj, bh, bz;
   HIPCHK(bp.alloc(batch)); HIPCHK(bit.alloc(rows * batch));
   HIPCHK(bd.alloc((size_t)7 * K * batch)); HIPCHK(bj.alloc((size_t)8 * K * batch)); HIPCHK(bh.alloc((size_t)10 * K * batch));
   HIPCHK(hipMemcpy(bp.d, p, batch * sizeof(ascent_params), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(bit.d, iterate, rows * batch * sizeof(double), hipMemcpyHostToDevice));
-  hipLaunchKernelGGL(k_eval_nodes, dim3((unsigned)((batch + 255) / 256), K), dim3(256), 0, 0, bp.d, (long)batch, K,
-                     bit.d, bd.d, bj.d, bh.d);
-  HIPCHK(hipGetLastError());
+  if (path == ASCENT_PATH_FUSED) {
+    hipLaunchKernelGGL(k_eval_nodes, dim3((unsigned)((batch + 255) / 256), K), dim3(256), 0, 0, bp.d, (long)batch, K,
+                       bit.d, bd.d, bj.d, bh.d);
+    HIPCHK(hipGetLastError());
+  } else {
+    rc = ensure_ws(device_id, pipeline_ws_bytes(K, (long)batch));
+    if (rc) return rc;
+    HIPCHK(bz.alloc(batch));                       // mu, delta_w: not used by the node evaluation
+    HIPCHK(hipMemset(bz.d, 0, batch * sizeof(double)));
+    rc = pipeline_probe(bp.d, (long)batch, K, (int)o->scheme, (int)o->formulation, g_ws[device_id].ws, bit.d, bz.d, bz.d,
+                        path == ASCENT_PATH_SPLIT_WIDE, false, nullptr, nullptr, bd.d, bj.d, bh.d, 0, g_err, sizeof g_err);
+    if (rc) return rc;
+  }
   HIPCHK(hipMemcpy(defects, bd.d, (size_t)7 * K * batch * sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(jac_blocks, bj.d, (size_t)8 * K * batch * sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(hess_blocks, bh.d, (size_t)10 * K * batch * sizeof(double), hipMemcpyDeviceToHost));
   return ASCENT_OK;
 }
 
-int ascent_kkt_step(const ascent_params *p, int64_t batch, const ascent_opts *o, const double *iterate,
-                    const double *mu, const double *delta_w, double *step, int32_t *inertia_out, int device_id) {
+int ascent_eval_nodes(const ascent_params *p, int64_t batch, const ascent_opts *o, const double *iterate,
+                      double *defects, double *jac_blocks, double *hess_blocks, int device_id) {
+  return ascent_eval_nodes_path(p, batch, o, iterate, defects, jac_blocks, hess_blocks, device_id, ASCENT_PATH_AUTO);
+}
+
+int ascent_kkt_step_path(const ascent_params *p, int64_t batch, const ascent_opts *o, const double *iterate,
+                         const double *mu, const double *delta_w, double *step, int32_t *inertia_out, int device_id,
+                         int path) {
   int rc = check_common(p, batch, o, device_id);
   if (rc) return rc;
   if (!iterate || !mu || !delta_w || !step || !inertia_out) { snprintf(g_err, sizeof g_err, "null pointer"); return ASCENT_E_ARG; }
-  if (o->scheme != 0 || o->formulation != 0) { snprintf(g_err, sizeof g_err, "ascent_kkt_step: scheme 0, formulation 0 only"); return ASCENT_E_ARG; }
+  if (path < ASCENT_PATH_AUTO || path > ASCENT_PATH_SPLIT_WIDE) { snprintf(g_err, sizeof g_err, "unknown path %d", path); return ASCENT_E_ARG; }
+  path = resolve_path(path, o, batch);
+  if (path == ASCENT_PATH_FUSED && (o->scheme != 0 || o->formulation != 0)) { snprintf(g_err, sizeof g_err, "the fused path has scheme 0, formulation 0 only"); return ASCENT_E_ARG; }
   std::lock_guard<std::mutex> lock(g_mu[device_id]);
   HIPCHK(hipSetDevice(device_id));
   const int K = o->n_nodes - 1;
   const size_t rows = 21 * (size_t)K + NSC;
   const int lpt = lanes_per_tile(batch);
-  rc = ensure_ws(device_id, ws_bytes(K, batch, lpt));
+  rc = ensure_ws(device_id, path == ASCENT_PATH_FUSED ? ws_bytes(K, batch, lpt) : pipeline_ws_bytes(K, (long)batch));
   if (rc) return rc;
   DevBuf<ascent_params> bp;
   DevBuf<double> bit, bmu, bdw, bst;
@@ -1184,12 +1223,23 @@ int ascent_kkt_step(const ascent_params *p, int64_t batch, const ascent_opts *o,
   HIPCHK(hipMemcpy(bmu.d, mu, batch * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(bdw.d, delta_w, batch * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemset(bst.d, 0, rows * batch * sizeof(double)));
-  hipLaunchKernelGGL(k_kkt_step, dim3((unsigned)((batch + lpt - 1) / lpt)), dim3(WAVE), 0, 0, bp.d, (long)batch, lpt, K,
-                     g_ws[device_id].ws, bit.d, bmu.d, bdw.d, bst.d, bin.d);
-  HIPCHK(hipGetLastError());
+  if (path == ASCENT_PATH_FUSED) {
+    hipLaunchKernelGGL(k_kkt_step, dim3((unsigned)((batch + lpt - 1) / lpt)), dim3(WAVE), 0, 0, bp.d, (long)batch, lpt, K,
+                       g_ws[device_id].ws, bit.d, bmu.d, bdw.d, bst.d, bin.d);
+    HIPCHK(hipGetLastError());
+  } else {
+    rc = pipeline_probe(bp.d, (long)batch, K, (int)o->scheme, (int)o->formulation, g_ws[device_id].ws, bit.d, bmu.d, bdw.d,
+                        path == ASCENT_PATH_SPLIT_WIDE, true, bst.d, bin.d, nullptr, nullptr, nullptr, 0, g_err, sizeof g_err);
+    if (rc) return rc;
+  }
   HIPCHK(hipMemcpy(step, bst.d, rows * batch * sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(inertia_out, bin.d, batch * sizeof(int), hipMemcpyDeviceToHost));
   return ASCENT_OK;
+}
+
+int ascent_kkt_step(const ascent_params *p, int64_t batch, const ascent_opts *o, const double *iterate,
+                    const double *mu, const double *delta_w, double *step, int32_t *inertia_out, int device_id) {
+  return ascent_kkt_step_path(p, batch, o, iterate, mu, delta_w, step, inertia_out, device_id, ASCENT_PATH_AUTO);
 }
 
 }  // extern "C"

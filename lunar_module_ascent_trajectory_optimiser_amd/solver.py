@@ -128,8 +128,10 @@ def solve_batch(params, nt: int = 200, tol: float = 1e-9, max_iter: int = 300, g
     return BatchResult(P, nt, traj, tf, status, iters, blob, L.ascent_last_kernel_ms(device))
 
 
-def eval_nodes(params, iterate: np.ndarray, nt: int = 200, device: int = 0):
-    """Per-step defects (7K,batch), Jacobian blocks (8K,batch), Hessian blocks (10K,batch)."""
+def eval_nodes(params, iterate: np.ndarray, nt: int = 200, device: int = 0, path="auto", scheme=0, formulation=0):
+    """Per-step defects (7K,batch), Jacobian blocks (8K,batch), Hessian blocks (10K,batch).
+    path: "auto" (the kernels solve_batch would run for this batch), "fused", "split_lane", "split_wide"
+    (enum ascent_path, include/ascent.h); the split paths take scheme 1 and formulation 1 as well."""
     L = _lib.load()
     P = pack(params)
     B, K = P.shape[0], nt - 1
@@ -137,13 +139,15 @@ def eval_nodes(params, iterate: np.ndarray, nt: int = 200, device: int = 0):
     if it.shape != (blob_rows(nt), B):
         raise ValueError("iterate has the wrong shape")
     d, j, h = np.empty((7 * K, B)), np.empty((8 * K, B)), np.empty((10 * K, B))
-    o = _opts(nt, 0, 1.0, 0, 0.0)
-    _lib.check(L.ascent_eval_nodes(_ptr(P), B, C.byref(o), _ptr(it), _ptr(d), _ptr(j), _ptr(h), device))
+    o = _opts(nt, 0, 1.0, 0, 0.0, scheme, formulation)
+    _lib.check(L.ascent_eval_nodes_path(_ptr(P), B, C.byref(o), _ptr(it), _ptr(d), _ptr(j), _ptr(h), device,
+                                        _lib.PATHS[path]))
     return d, j, h
 
 
-def kkt_step(params, iterate: np.ndarray, mu, delta_w, nt: int = 200, device: int = 0):
-    """One Newton step of the barrier problem at `iterate` -> (step blob, inertia flags)."""
+def kkt_step(params, iterate: np.ndarray, mu, delta_w, nt: int = 200, device: int = 0, path="auto", scheme=0,
+             formulation=0):
+    """One Newton step of the barrier problem at `iterate` -> (step blob, inertia flags); `path` as in eval_nodes."""
     L = _lib.load()
     P = pack(params)
     B = P.shape[0]
@@ -154,14 +158,16 @@ def kkt_step(params, iterate: np.ndarray, mu, delta_w, nt: int = 200, device: in
     dw = np.ascontiguousarray(np.broadcast_to(np.asarray(delta_w, dtype=np.float64), (B,)))
     step = np.empty_like(it)
     inertia = np.empty(B, dtype=np.int32)
-    o = _opts(nt, 0, 1.0, 0, 0.0)
-    _lib.check(L.ascent_kkt_step(_ptr(P), B, C.byref(o), _ptr(it), _ptr(mu), _ptr(dw), _ptr(step), _ptr(inertia), device))
+    o = _opts(nt, 0, 1.0, 0, 0.0, scheme, formulation)
+    _lib.check(L.ascent_kkt_step_path(_ptr(P), B, C.byref(o), _ptr(it), _ptr(mu), _ptr(dw), _ptr(step), _ptr(inertia),
+                                      device, _lib.PATHS[path]))
     return step, inertia
 
 
 def solve_batch_torch(params_t, nt: int = 200, tol: float = 1e-9, max_iter: int = 300, guess_t=None,
                       warm_start: int = 0, mu_init: float = 0.0, want_traj: bool = True, want_blob: bool = False,
-                      out: dict | None = None, sync: bool = False, coarse_nodes: int = 0) -> dict:
+                      out: dict | None = None, sync: bool = False, coarse_nodes: int = 0, scheme=0,
+                      formulation=0) -> dict:
     """Device-resident variant: `params_t` is a torch float64 CUDA tensor (batch,16); all outputs are
     torch CUDA tensors (allocated here unless passed in `out`).  Enqueues on torch's current stream
     and returns without waiting unless sync=True.  torch is only the owner of device memory/streams."""
@@ -177,13 +183,22 @@ def solve_batch_torch(params_t, nt: int = 200, tol: float = 1e-9, max_iter: int 
         t = out.get(name)
         if t is None:
             t = out[name] = torch.empty(shape, dtype=dtype, device=dev)
+        elif not (t.device == dev and t.dtype == dtype and tuple(t.shape) == tuple(shape) and t.is_contiguous()):
+            raise ValueError(f"out[{name!r}] must be a contiguous {dtype} tensor of shape {tuple(shape)} on {dev}")
         return t
+    if params_t.dim() != 2 or params_t.shape[1] != 16:
+        raise ValueError("params_t must have shape (batch, 16)")
+    if warm_start not in (0, 1, 2) or (warm_start and guess_t is None):
+        raise ValueError("warm_start 1/2 needs guess_t")
+    if guess_t is not None and not (guess_t.device == dev and guess_t.dtype == torch.float64 and guess_t.is_contiguous()
+                                    and tuple(guess_t.shape) == (rows, B)):
+        raise ValueError(f"guess_t must be a contiguous float64 tensor of shape {(rows, B)} on {dev}")
     tf = buf("tf", (B,), torch.float64)
     status = buf("status", (B,), torch.int32)
     iters = buf("iters", (B,), torch.int32)
     traj = buf("traj", (10, nt, B), torch.float64) if want_traj else None
     blob = buf("blob", (rows, B), torch.float64) if want_blob else None
-    o = _opts(nt, max_iter, tol, warm_start, mu_init, coarse_nodes=coarse_nodes)
+    o = _opts(nt, max_iter, tol, warm_start, mu_init, scheme, formulation, coarse_nodes)
     stream = torch.cuda.current_stream(dev).cuda_stream
     _lib.check(L.ascent_solve_batch(params_t.data_ptr(), B, C.byref(o),
                                     guess_t.data_ptr() if guess_t is not None else None,

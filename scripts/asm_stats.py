@@ -1,20 +1,42 @@
-"""Developer tool: per-function instruction / register statistics of the gfx950 code object."""
-import os, re, subprocess, sys, tempfile
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-src = os.path.join(ROOT, "lunar_module_ascent_trajectory_optimiser_amd", "csrc", os.environ.get("ASM_SRC", "ascent_solver.hip"))
-d = tempfile.mkdtemp()
-subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I", os.path.join(ROOT, "include"),
-                "-save-temps", "-c", "-o", "x.o", src] + sys.argv[1:], cwd=d, check=True, stderr=subprocess.DEVNULL)
-s = open(os.path.join(d, [f for f in os.listdir(d) if f.endswith("gfx950.s")][0])).read()
-if os.environ.get("KEEP_ASM"):
-    open(os.environ["KEEP_ASM"], "w").write(s)
-for f in re.split(r"\n(?=_Z[\w]+:)", s):
-    m = re.match(r"(_Z\w+):", f)
-    if not m:
-        continue
-    c = lambda pat: len(re.findall(pat, f))
-    g = lambda pat: (re.search(pat, f) or [None, "?"])[1]
-    P = dict(f64=r"v_(fma|mul|add)_f64", valu=r"\n\s+v_", salu=r"\n\s+s_", gld="global_load", gst="global_store",
-             flat="flat_(load|store)", scr="scratch_(load|store)", acc="v_accvgpr", wait="s_waitcnt")
-    R = dict(vgpr=r"; NumVgprs: (\d+)", agpr=r"; NumAgprs: (\d+)", scratch=r"; ScratchSize: (\d+)")
-    print(m.group(1)[14:60].ljust(46), " ".join(f"{k} {c(v):5d}" for k, v in P.items()), " ".join(f"{k} {g(v)}" for k, v in R.items()))
+#!/usr/bin/env python3
+"""Per-function register / scratch / occupancy table of a gfx950 assembly listing made with
+`hipcc --offload-arch=gfx950 -O3 -std=c++17 -I include -save-temps -c <file.hip>` (the *-gfx950.s file)."""
+import re
+import subprocess
+import sys
+
+
+def demangle(n):
+    try:
+        return subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-cxxfilt", n], capture_output=True, text=True).stdout.strip().split("(")[0]
+    except OSError:
+        return n
+
+
+def main(path):
+    # the statistics block of a function follows its "-- End function" marker and ends with "; Occupancy"
+    name, rows, cur = None, [], None
+    for line in open(path):
+        m = re.match(r"^(_Z\w+):", line)
+        if m:
+            name = m.group(1)
+            continue
+        if "-- End function" in line and name:
+            cur = {}
+            continue
+        if cur is not None:
+            m = re.match(r"^; (NumVgprs|NumAgprs|ScratchSize|Occupancy|LDSByteSize|codeLenInByte)\D*(\d+)", line)
+            if m:
+                cur[m.group(1)] = int(m.group(2))
+                if m.group(1) in ("Occupancy",) or (m.group(1) == "ScratchSize" and False):
+                    rows.append((name, cur)); cur = None; name = None
+            elif line.startswith("\t.") and "ScratchSize" in cur:      # a device function's block has no Occupancy line
+                rows.append((name, cur)); cur = None; name = None
+    print(f"{'function':62s} {'VGPR':>5s} {'AGPR':>5s} {'scratch':>8s} {'occ':>4s} {'LDS':>7s} {'code':>7s}")
+    for n, c in rows:
+        print(f"{demangle(n)[-62:]:62s} {c.get('NumVgprs', 0):5d} {c.get('NumAgprs', 0):5d} {c.get('ScratchSize', 0):8d} "
+              f"{c.get('Occupancy', 0):4d} {c.get('LDSByteSize', 0):7d} {c.get('codeLenInByte', 0):7d}")
+
+
+if __name__ == "__main__":
+    main(sys.argv[1])

@@ -37,6 +37,66 @@ def _worker(rank, world, port, nt, q):
     dist.destroy_process_group()
 
 
+def _worker_edge(rank, world, port, nt, q, mode):
+    """mode "few": 2 problems on 3 ranks (rank 2 has an empty shard).  mode "fail": rank 1's solver raises."""
+    sys.path.insert(0, ROOT)
+    import torch.distributed as dist
+    from lunar_module_ascent_trajectory_optimiser_amd import sweep_isp_drymass
+    from lunar_module_ascent_trajectory_optimiser_amd.distributed import solve_sharded
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+
+    def solver(P, **kw):
+        if mode == "fail" and rank == 1:
+            raise RuntimeError("libascent error -4: workspace hipMalloc")     # what a per-rank library error looks like
+        return _oracle_solver(P, **kw)
+
+    S = sweep_isp_drymass(2, 2)[:2] if mode == "few" else sweep_isp_drymass(2, 2)
+    try:
+        out = solve_sharded(S, nt=nt, tol=1e-8, solver=solver)
+        q.put((rank, "ok", None if out is None else (out["tf"], out["status"])))
+    except RuntimeError as e:
+        q.put((rank, "raised", str(e)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run(world, nt, mode):
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_edge, args=(r, world, port, nt, q, mode)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = dict()
+    for _ in range(world):
+        r, what, payload = q.get(timeout=180)
+        got[r] = (what, payload)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    return got
+
+
+def test_more_ranks_than_problems_does_not_hang(coracle):
+    """n < world: the rank with the empty shard contributes padding to the gather instead of calling the solver with
+    batch 0 (which the library refuses) and leaving the other ranks blocked in the collective."""
+    from lunar_module_ascent_trajectory_optimiser_amd import sweep_isp_drymass
+    got = _run(3, 30, "few")
+    assert all(w == "ok" for w, _ in got.values())
+    tf, status = got[0][1]
+    ref = coracle.solve_batch(sweep_isp_drymass(2, 2)[:2], 30, 300, 1e-8)
+    assert np.array_equal(tf, ref["tf"]) and np.array_equal(status, ref["status"])
+    assert got[1][1] is None and got[2][1] is None
+
+
+def test_failing_rank_joins_the_gather_and_is_reported():
+    """A rank whose solver raises still joins the collective; the error surfaces on that rank and on rank 0."""
+    got = _run(2, 30, "fail")
+    assert got[1][0] == "raised" and "libascent error" in got[1][1]
+    assert got[0][0] == "raised" and "rank(s) [1]" in got[0][1]
+
+
 def test_shard_indices_partition():
     from lunar_module_ascent_trajectory_optimiser_amd.distributed import shard_indices
     for n, w in ((7, 2), (4096, 8), (5, 8), (262144, 8)):

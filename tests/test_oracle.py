@@ -291,3 +291,20 @@ def test_c_oracle_nested_iteration_agrees_with_single_grid():
     u = f[7 * Kf:8 * Kf]
     assert np.abs(u[tf_ >= 1 / Kc] - (0.25 + 0.5 * tf_[tf_ >= 1 / Kc])).max() < 1e-14      # constant before the first coarse node
     assert np.array_equal(f[21 * Kf:], np.arange(1, 11))
+
+
+def test_c_oracle_matches_independent_sweep_corners(coracle):
+    """tests/golden/sweep_corners.json holds the numpy generic-LU oracle's solutions (scripts/make_sweep_corners.py) of the
+    four corners of the config-3 box and the sixteen corners of the config-4 box: the stage-structured C oracle must
+    land on the same optima away from the nominal problem too (t_f to 1e-9; the end of the singular arc is only weakly
+    determined by a KKT point, so states to 1e-6)."""
+    import json, os
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "sweep_corners.json")))
+    for grp, n in (("config3", 4), ("config4", 16)):
+        assert len(fx[grp]) == n
+        P = np.array([[e["params"][f] for f in coracle.PARAM_FIELDS] for e in fx[grp]])
+        r = coracle.solve_batch(P, fx["nt"], 300, 1e-10)
+        assert np.all(r["status"] == 0)
+        assert np.abs(r["tf"] - np.array([e["tf"] for e in fx[grp]])).max() <= 1e-9
+        for fi, key in ((0, "final_x"), (1, "final_y"), (2, "final_xdot"), (3, "final_ydot"), (6, "final_angle"), (9, "final_mass")):
+            assert np.abs(r["traj"][:, fi, -1] - np.array([e[key] for e in fx[grp]])).max() <= 1e-6
