@@ -49,7 +49,9 @@ typedef struct ascent_params {
 typedef struct ascent_opts {
   int32_t n_nodes;     /* :20  nt, number of grid points (tau_k = k/(nt-1), :21), 3 .. 65536 */
   int32_t scheme;      /* 0 = NODES=2 two-point collocation = backward Euler (:25);
-                          1 = trapezoid, control held over the step (not a reference scheme) */
+                          1 = trapezoid, control held over the step (not a reference scheme);
+                          2 = Hermite-Simpson (compressed form, control held over the step; the method
+                              source the reference's report cites, PDF p3/p25) -- dense-block solver path */
   int32_t max_iter;    /* :28  interior-point iteration cap                              */
   int32_t warm_start;  /* 0 = built-in cold-start guess, 1 = primal part of `guess`,
                           2 = full primal-dual `guess` (multipliers kept)                */
@@ -65,6 +67,13 @@ typedef struct ascent_opts {
                            recursively; coarse levels are solved to max(tol, 1e-3)), -1 = off (single grid),
                            > 0 = that many coarse nodes (two levels).
                            iters_out counts the iterations of all levels.                              */
+  int32_t terminal;     /* 0 = the reference's terminal speed (:72-78: circular speed of the MEAN radius, imposed at
+                               r_peri with r.v = 0, :158-173);
+                           1 = the (r_peri, r_apo) ellipse proper (README.md:7): same three constraints with the vis-viva
+                               speed at the periapsis of that ellipse, so that the burnout orbit is the target ellipse and
+                               ascent_coast_batch's coast arc ends at its apoapsis                          */
+  int32_t solver_path;  /* 0 = automatic (hand-tuned sparse kernels for schemes 0/1, dense-block path for scheme 2);
+                           ASCENT_PATH_DENSE = the dense-block path for any scheme (formulation 0 only)       */
 } ascent_opts;
 
 enum ascent_status {           /* function return codes */
@@ -150,13 +159,33 @@ int ascent_kkt_step(const ascent_params *p, int64_t batch, const ascent_opts *o,
  *   ASCENT_PATH_SPLIT_WIDE  q_trial_eval -> q_factor_wide -> q_forward_wide -> q_local -> q_adjoint_wide
  * The split paths take schemes 0/1 and formulations 0/1.  For scheme 1 (trapezoid) `defects` is the trapezoid
  * defect and the Hessian block of node k is weighted by -(h*T*tf/2)*(lambda_k + lambda_{k+1}). */
-enum ascent_path { ASCENT_PATH_AUTO = 0, ASCENT_PATH_FUSED = 1, ASCENT_PATH_SPLIT_LANE = 2, ASCENT_PATH_SPLIT_WIDE = 3 };
+enum ascent_path { ASCENT_PATH_AUTO = 0, ASCENT_PATH_FUSED = 1, ASCENT_PATH_SPLIT_LANE = 2, ASCENT_PATH_SPLIT_WIDE = 3,
+                   ASCENT_PATH_DENSE = 4 /* d_eval -> d_newton, one wavefront per NLP on dense 8x8 blocks: schemes 0/1/2 */ };
 int ascent_eval_nodes_path(const ascent_params *p, int64_t batch, const ascent_opts *o,
                            const double *iterate, double *defects, double *jac_blocks,
                            double *hess_blocks, int device_id, int path);
 int ascent_kkt_step_path(const ascent_params *p, int64_t batch, const ascent_opts *o,
                          const double *iterate, const double *mu, const double *delta_w, double *step,
                          int32_t *inertia_out, int device_id, int path);
+
+/* Dense stage records as the dense-block path's node kernel (d_eval) leaves them at `iterate` (parity surface for the
+ * Hermite-Simpson derivatives): records[batch][K][6][64] doubles, six row-major 8x8 grids per step (7 states + one
+ * padding slot): 0 = d c_k/d z_{k-1}, 1 = d c_k/d z_k, 2/3/4 = the (z_{k-1},z_{k-1}) / (z_{k-1},z_k) / (z_k,z_k) blocks of the
+ * Hessian of lambda_k'c_k, 5 = vectors by row: c_k, d c_k/du_k, d c_k/d tf, and the (z_{k-1},tf), (z_k,tf) Hessian
+ * columns.  Host pointers. */
+int ascent_dense_records(const ascent_params *p, int64_t batch, const ascent_opts *o, const double *iterate,
+                         double *records, int device_id);
+
+/* The coast arc after the burn (second phase of BASELINE config 5; the reference's v1 script propagated it with
+ * explicit Euler, PDF p28-29): Kepler-exact two-body propagation of every problem's final state to the next
+ * apoapsis of its orbit, sampled uniformly in time.
+ * final_state [4][batch]: scaled x, y, xdot, ydot of the last node (rows 0..3 of traj_out at node n_nodes-1);
+ * coast_traj [4][coast_nodes+1][batch] (same scaled units; node 0 = the burnout state);
+ * coast_tf [batch]: coast duration / T_scale;  apsides [2][batch]: periapsis and apoapsis altitude above R0, m.
+ * Host or device pointers (ptr_is_device), optional stream. */
+int ascent_coast_batch(const ascent_params *p, int64_t batch, const double *final_state, int32_t coast_nodes,
+                       double *coast_traj, double *coast_tf, double *apsides, int device_id,
+                       void *hip_stream_or_null, int ptr_is_device);
 
 /* Device time (ms) of the solve kernel of the most recent ascent_solve_batch on this device,
  * measured with HIP events recorded on the launch stream around the kernel; waits for that

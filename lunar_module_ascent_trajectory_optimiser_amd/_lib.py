@@ -26,13 +26,14 @@ class AscentOptsC(C.Structure):
     """struct ascent_opts (include/ascent.h)."""
     _fields_ = [("n_nodes", C.c_int32), ("scheme", C.c_int32), ("max_iter", C.c_int32),
                 ("warm_start", C.c_int32), ("tol", C.c_double), ("mu_init", C.c_double),
-                ("formulation", C.c_int32), ("coarse_nodes", C.c_int32)]
+                ("formulation", C.c_int32), ("coarse_nodes", C.c_int32), ("terminal", C.c_int32),
+                ("solver_path", C.c_int32)]
 
 
 SYMBOLS = ("ascent_version", "ascent_device_count", "ascent_strerror", "ascent_solve_batch",
            "ascent_eval_nodes", "ascent_kkt_step", "ascent_eval_nodes_path", "ascent_kkt_step_path",
-           "ascent_last_kernel_ms")
-PATHS = {"auto": 0, "fused": 1, "split_lane": 2, "split_wide": 3}     # enum ascent_path
+           "ascent_dense_records", "ascent_coast_batch", "ascent_last_kernel_ms")
+PATHS = {"auto": 0, "fused": 1, "split_lane": 2, "split_wide": 3, "dense": 4}     # enum ascent_path
 
 _lib = None
 
@@ -73,6 +74,11 @@ def load():
     L.ascent_eval_nodes_path.argtypes = L.ascent_eval_nodes.argtypes + [C.c_int]
     L.ascent_kkt_step_path.restype = C.c_int
     L.ascent_kkt_step_path.argtypes = L.ascent_kkt_step.argtypes + [C.c_int]
+    L.ascent_dense_records.restype = C.c_int
+    L.ascent_dense_records.argtypes = [C.c_void_p, C.c_int64, C.POINTER(AscentOptsC), C.c_void_p, C.c_void_p, C.c_int]
+    L.ascent_coast_batch.restype = C.c_int
+    L.ascent_coast_batch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                     C.c_int, C.c_void_p, C.c_int]
     _lib = L
     return L
 

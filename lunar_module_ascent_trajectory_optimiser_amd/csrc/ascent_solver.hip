@@ -30,6 +30,7 @@
 #include "ascent_device.hpp"
 #include "ascent_tile.hpp"
 #include "ascent_pipeline.hpp"
+#include "ascent_dense.hpp"
 
 using namespace ascent;
 
@@ -891,6 +892,25 @@ __global__ __launch_bounds__(WAVE) void k_add_iters(int *iters, const int *acc, 
   if (p < batch) iters[p] += acc[p];
 }
 
+// ascent_opts.terminal = 1: the terminal speed becomes the vis-viva speed at the periapsis of the (r_peri, r_apo) ellipse.
+// Every kernel derives its constants from the parameter struct (derive(): circular speed of the mean radius, LO:72-78), so
+// the solvers run on a copy whose r_apo is replaced by the apoapsis r' for which that mean-radius formula gives the wanted
+// speed:  GM / (R0 + (r_peri + r')/2) = GM (2/rp - 2/(rp + ra)).
+__global__ __launch_bounds__(WAVE) void k_terminal_params(const ascent_params *in, ascent_params *out, long batch) {
+  const long p = (long)blockIdx.x * WAVE + threadIdx.x;
+  if (p >= batch) return;
+  ascent_params q = in[p];
+  const double rp = q.R0 + q.r_peri, ra = q.R0 + q.r_apo;
+  q.r_apo = 2.0 * (1.0 / (2.0 / rp - 2.0 / (rp + ra)) - q.R0) - q.r_peri;
+  out[p] = q;
+}
+
+bool use_dense_path(const ascent_opts *o) {
+  if (o->scheme == 2 || o->solver_path == ASCENT_PATH_DENSE) return true;
+  const char *e = getenv("ASCENT_PIPELINE");
+  return e && !strcmp(e, "dense") && o->formulation == 0;
+}
+
 struct DeviceWs {
   double *ws = nullptr;
   size_t bytes = 0;
@@ -901,7 +921,8 @@ struct DeviceWs {
   size_t sol_n = 0, gss_n = 0, int_n = 0;
   int *st_c = nullptr, *it_c = nullptr, *acc = nullptr;
   // staging buffers of host-pointer calls, kept between calls (the GEKKO-style front end solves one NLP per call)
-  ascent_params *h_p = nullptr;
+  ascent_params *h_p = nullptr, *t_p = nullptr;
+  size_t t_p_n = 0;
   double *h_guess = nullptr, *h_traj = nullptr, *h_tf = nullptr, *h_blob = nullptr;
   int *h_status = nullptr, *h_iters = nullptr;
   size_t h_p_n = 0, h_guess_n = 0, h_traj_n = 0, h_tf_n = 0, h_blob_n = 0, h_status_n = 0, h_iters_n = 0;
@@ -969,9 +990,12 @@ int check_common(const ascent_params *p, int64_t batch, const ascent_opts *o, in
   if (!p || !o || batch <= 0) { snprintf(g_err, sizeof g_err, "null params/opts or batch <= 0"); return ASCENT_E_ARG; }
   if (o->n_nodes < 3 || o->n_nodes > 65536) { snprintf(g_err, sizeof g_err, "n_nodes out of range (3 .. 65536)"); return ASCENT_E_ARG; }
   if (o->formulation != 0 && o->formulation != 1) { snprintf(g_err, sizeof g_err, "formulation %d not supported (0 = current script, 1 = v1 script)", o->formulation); return ASCENT_E_ARG; }
-  if (o->formulation == 1 && o->scheme != 0) { snprintf(g_err, sizeof g_err, "formulation 1 is available with scheme 0 only"); return ASCENT_E_ARG; }
+  if (o->formulation == 1 && o->scheme != 0 && o->scheme != 2) { snprintf(g_err, sizeof g_err, "formulation 1 is available with scheme 0 only"); return ASCENT_E_ARG; }
   if (o->coarse_nodes != -1 && o->coarse_nodes != 0 && (o->coarse_nodes < 3 || o->coarse_nodes >= o->n_nodes)) { snprintf(g_err, sizeof g_err, "coarse_nodes must be -1 (off), 0 (automatic) or in [3, n_nodes)"); return ASCENT_E_ARG; }
-  if (o->scheme != 0 && o->scheme != 1) { snprintf(g_err, sizeof g_err, "scheme %d not supported (0 = backward Euler, the reference's NODES=2; 1 = trapezoid)", o->scheme); return ASCENT_E_ARG; }
+  if (o->scheme < 0 || o->scheme > 2) { snprintf(g_err, sizeof g_err, "scheme %d not supported (0 = backward Euler, the reference's NODES=2; 1 = trapezoid; 2 = Hermite-Simpson)", o->scheme); return ASCENT_E_ARG; }
+  if (o->terminal != 0 && o->terminal != 1) { snprintf(g_err, sizeof g_err, "terminal %d not supported (0 = reference, 1 = ellipse proper)", o->terminal); return ASCENT_E_ARG; }
+  if (o->solver_path != ASCENT_PATH_AUTO && o->solver_path != ASCENT_PATH_DENSE) { snprintf(g_err, sizeof g_err, "solver_path must be 0 (automatic) or ASCENT_PATH_DENSE"); return ASCENT_E_ARG; }
+  if ((o->scheme == 2 || o->solver_path == ASCENT_PATH_DENSE) && o->formulation != 0) { snprintf(g_err, sizeof g_err, "the dense-block path (scheme 2 / ASCENT_PATH_DENSE) has formulation 0 only"); return ASCENT_E_ARG; }
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { snprintf(g_err, sizeof g_err, "no HIP device available"); return ASCENT_E_NODEVICE; }
   if (device_id < 0 || device_id >= n || device_id >= MAX_DEV) { snprintf(g_err, sizeof g_err, "device %d of %d", device_id, n); return ASCENT_E_NODEVICE; }
@@ -1043,8 +1067,9 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
   const size_t rows = 21 * (size_t)K + NSC;
   const int lpt = lanes_per_tile(batch);
   // the trapezoid scheme and the v1 formulation exist in the split pipeline only
+  const bool dense = use_dense_path(o);
   const bool split = o->scheme == 1 || o->formulation == 1 || use_split_pipeline(batch);
-  rc = ensure_ws(device_id, split ? pipeline_ws_bytes(K, (long)batch) : ws_bytes(K, batch, lpt));
+  rc = ensure_ws(device_id, dense ? dense_ws_bytes(K, (long)batch) : split ? pipeline_ws_bytes(K, (long)batch) : ws_bytes(K, batch, lpt));
   if (rc) return rc;
   DeviceWs &w = g_ws[device_id];
   const double mu0 = o->mu_init > 0 ? o->mu_init : (o->warm_start ? 1e-4 : 0.1);
@@ -1072,6 +1097,12 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
     dstatus = w.h_status;
     if ((rc = grow(w.h_iters, w.h_iters_n, (size_t)batch))) return rc;
     diters = w.h_iters;
+  }
+  if (o->terminal == 1) {
+    if ((rc = grow(w.t_p, w.t_p_n, (size_t)batch))) return rc;
+    hipLaunchKernelGGL(k_terminal_params, dim3((unsigned)((batch + WAVE - 1) / WAVE)), dim3(WAVE), 0, stream, dp, w.t_p, (long)batch);
+    HIPCHK(hipGetLastError());
+    dp = w.t_p;
   }
   const unsigned grid = (unsigned)((batch + lpt - 1) / lpt);
   // grid levels of the nested iteration, finest first (levels[0] = n_nodes); one level = a plain solve
@@ -1110,7 +1141,11 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
     const double tol_l = fin ? o->tol : fmax(o->tol, NESTED_COARSE_TOL);
     double *traj_l = fin ? dtraj : nullptr, *tf_l = fin ? dtf : w.tfc, *blob_l = fin ? dblob : w.sol;
     int *st_l = fin ? dstatus : w.st_c, *it_l = fin ? diters : w.it_c;
-    if (split) {
+    if (dense) {
+      rc = dense_run(dp, (long)batch, Kl, (int)o->scheme, 0, w.ws, g_l, warm_l, (int)o->max_iter, tol_l, mu_l, traj_l, tf_l, st_l,
+                     it_l, blob_l, stream, g_err, sizeof g_err);
+      if (rc) return rc;
+    } else if (split) {
       rc = pipeline_run(dp, (long)batch, Kl, (int)o->scheme, (int)o->formulation, w.ws, g_l, warm_l, (int)o->max_iter, tol_l, mu_l,
                         traj_l, tf_l, st_l, it_l, blob_l, stream, nullptr, g_err, sizeof g_err);
       if (rc) return rc;
@@ -1146,6 +1181,7 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
 // which kernels a parity-surface call runs: an explicit path, or (AUTO) the one ascent_solve_batch would take
 static int resolve_path(int path, const ascent_opts *o, int64_t batch) {
   if (path == ASCENT_PATH_AUTO) {
+    if (use_dense_path(o)) return ASCENT_PATH_DENSE;
     const bool split = o->scheme == 1 || o->formulation == 1 || use_split_pipeline(batch);
     if (!split) return ASCENT_PATH_FUSED;
     bool wide = batch <= 4096;
@@ -1160,8 +1196,10 @@ int ascent_eval_nodes_path(const ascent_params *p, int64_t batch, const ascent_o
   int rc = check_common(p, batch, o, device_id);
   if (rc) return rc;
   if (!iterate || !defects || !jac_blocks || !hess_blocks) { snprintf(g_err, sizeof g_err, "null pointer"); return ASCENT_E_ARG; }
-  if (path < ASCENT_PATH_AUTO || path > ASCENT_PATH_SPLIT_WIDE) { snprintf(g_err, sizeof g_err, "unknown path %d", path); return ASCENT_E_ARG; }
+  if (path < ASCENT_PATH_AUTO || path > ASCENT_PATH_DENSE) { snprintf(g_err, sizeof g_err, "unknown path %d", path); return ASCENT_E_ARG; }
   path = resolve_path(path, o, batch);
+  if (path == ASCENT_PATH_DENSE) { snprintf(g_err, sizeof g_err, "the dense-block path exposes its node evaluation through ascent_dense_records"); return ASCENT_E_ARG; }
+  if (o->scheme == 2) { snprintf(g_err, sizeof g_err, "scheme 2 exists in the dense-block path only"); return ASCENT_E_ARG; }
   if (path == ASCENT_PATH_FUSED && (o->scheme != 0 || o->formulation != 0)) { snprintf(g_err, sizeof g_err, "the fused path has scheme 0, formulation 0 only"); return ASCENT_E_ARG; }
   std::lock_guard<std::mutex> lock(g_mu[device_id]);
   HIPCHK(hipSetDevice(device_id));
@@ -1203,15 +1241,18 @@ int ascent_kkt_step_path(const ascent_params *p, int64_t batch, const ascent_opt
   int rc = check_common(p, batch, o, device_id);
   if (rc) return rc;
   if (!iterate || !mu || !delta_w || !step || !inertia_out) { snprintf(g_err, sizeof g_err, "null pointer"); return ASCENT_E_ARG; }
-  if (path < ASCENT_PATH_AUTO || path > ASCENT_PATH_SPLIT_WIDE) { snprintf(g_err, sizeof g_err, "unknown path %d", path); return ASCENT_E_ARG; }
+  if (path < ASCENT_PATH_AUTO || path > ASCENT_PATH_DENSE) { snprintf(g_err, sizeof g_err, "unknown path %d", path); return ASCENT_E_ARG; }
   path = resolve_path(path, o, batch);
+  if (o->scheme == 2 && path != ASCENT_PATH_DENSE) { snprintf(g_err, sizeof g_err, "scheme 2 exists in the dense-block path only"); return ASCENT_E_ARG; }
+  if (path == ASCENT_PATH_DENSE && o->formulation != 0) { snprintf(g_err, sizeof g_err, "the dense-block path has formulation 0 only"); return ASCENT_E_ARG; }
   if (path == ASCENT_PATH_FUSED && (o->scheme != 0 || o->formulation != 0)) { snprintf(g_err, sizeof g_err, "the fused path has scheme 0, formulation 0 only"); return ASCENT_E_ARG; }
   std::lock_guard<std::mutex> lock(g_mu[device_id]);
   HIPCHK(hipSetDevice(device_id));
   const int K = o->n_nodes - 1;
   const size_t rows = 21 * (size_t)K + NSC;
   const int lpt = lanes_per_tile(batch);
-  rc = ensure_ws(device_id, path == ASCENT_PATH_FUSED ? ws_bytes(K, batch, lpt) : pipeline_ws_bytes(K, (long)batch));
+  rc = ensure_ws(device_id, path == ASCENT_PATH_DENSE ? dense_ws_bytes(K, (long)batch)
+                            : path == ASCENT_PATH_FUSED ? ws_bytes(K, batch, lpt) : pipeline_ws_bytes(K, (long)batch));
   if (rc) return rc;
   DevBuf<ascent_params> bp;
   DevBuf<double> bit, bmu, bdw, bst;
@@ -1223,7 +1264,15 @@ int ascent_kkt_step_path(const ascent_params *p, int64_t batch, const ascent_opt
   HIPCHK(hipMemcpy(bmu.d, mu, batch * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemcpy(bdw.d, delta_w, batch * sizeof(double), hipMemcpyHostToDevice));
   HIPCHK(hipMemset(bst.d, 0, rows * batch * sizeof(double)));
-  if (path == ASCENT_PATH_FUSED) {
+  if (o->terminal == 1) {     // in place on the private copy
+    hipLaunchKernelGGL(k_terminal_params, dim3((unsigned)((batch + WAVE - 1) / WAVE)), dim3(WAVE), 0, 0, bp.d, bp.d, (long)batch);
+    HIPCHK(hipGetLastError());
+  }
+  if (path == ASCENT_PATH_DENSE) {
+    rc = dense_probe(bp.d, (long)batch, K, (int)o->scheme, 0, g_ws[device_id].ws, bit.d, bmu.d, bdw.d, true, bst.d, bin.d, nullptr,
+                     0, g_err, sizeof g_err);
+    if (rc) return rc;
+  } else if (path == ASCENT_PATH_FUSED) {
     hipLaunchKernelGGL(k_kkt_step, dim3((unsigned)((batch + lpt - 1) / lpt)), dim3(WAVE), 0, 0, bp.d, (long)batch, lpt, K,
                        g_ws[device_id].ws, bit.d, bmu.d, bdw.d, bst.d, bin.d);
     HIPCHK(hipGetLastError());
@@ -1234,6 +1283,68 @@ int ascent_kkt_step_path(const ascent_params *p, int64_t batch, const ascent_opt
   }
   HIPCHK(hipMemcpy(step, bst.d, rows * batch * sizeof(double), hipMemcpyDeviceToHost));
   HIPCHK(hipMemcpy(inertia_out, bin.d, batch * sizeof(int), hipMemcpyDeviceToHost));
+  for (int64_t q = 0; q < batch; q++) inertia_out[q] = inertia_out[q] != 0;     // (the dense path reports a status code)
+  return ASCENT_OK;
+}
+
+int ascent_dense_records(const ascent_params *p, int64_t batch, const ascent_opts *o, const double *iterate,
+                         double *records, int device_id) {
+  int rc = check_common(p, batch, o, device_id);
+  if (rc) return rc;
+  if (!iterate || !records) { snprintf(g_err, sizeof g_err, "null pointer"); return ASCENT_E_ARG; }
+  if (o->formulation != 0) { snprintf(g_err, sizeof g_err, "the dense-block path has formulation 0 only"); return ASCENT_E_ARG; }
+  std::lock_guard<std::mutex> lock(g_mu[device_id]);
+  HIPCHK(hipSetDevice(device_id));
+  const int K = o->n_nodes - 1;
+  const size_t rows = 21 * (size_t)K + NSC, nrec = (size_t)batch * K * 6 * 64;
+  rc = ensure_ws(device_id, dense_ws_bytes(K, (long)batch));
+  if (rc) return rc;
+  DevBuf<ascent_params> bp;
+  DevBuf<double> bit, bz, br;
+  HIPCHK(bp.alloc(batch)); HIPCHK(bit.alloc(rows * batch)); HIPCHK(bz.alloc(batch)); HIPCHK(br.alloc(nrec));
+  HIPCHK(hipMemcpy(bp.d, p, batch * sizeof(ascent_params), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(bit.d, iterate, rows * batch * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(bz.d, 0, batch * sizeof(double)));
+  if (o->terminal == 1) {
+    hipLaunchKernelGGL(k_terminal_params, dim3((unsigned)((batch + WAVE - 1) / WAVE)), dim3(WAVE), 0, 0, bp.d, bp.d, (long)batch);
+    HIPCHK(hipGetLastError());
+  }
+  rc = dense_probe(bp.d, (long)batch, K, (int)o->scheme, 0, g_ws[device_id].ws, bit.d, bz.d, bz.d, false, nullptr, nullptr, br.d, 0,
+                   g_err, sizeof g_err);
+  if (rc) return rc;
+  HIPCHK(hipMemcpy(records, br.d, nrec * sizeof(double), hipMemcpyDeviceToHost));
+  return ASCENT_OK;
+}
+
+int ascent_coast_batch(const ascent_params *p, int64_t batch, const double *final_state, int32_t coast_nodes,
+                       double *coast_traj, double *coast_tf, double *apsides, int device_id, void *stream_,
+                       int ptr_is_device) {
+  if (!p || batch <= 0 || !final_state || !coast_traj || !coast_tf || !apsides) { snprintf(g_err, sizeof g_err, "null pointer or batch <= 0"); return ASCENT_E_ARG; }
+  if (coast_nodes < 1 || coast_nodes > 65535) { snprintf(g_err, sizeof g_err, "coast_nodes out of range (1 .. 65535)"); return ASCENT_E_ARG; }
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { snprintf(g_err, sizeof g_err, "no HIP device available"); return ASCENT_E_NODEVICE; }
+  if (device_id < 0 || device_id >= n || device_id >= MAX_DEV) { snprintf(g_err, sizeof g_err, "device %d of %d", device_id, n); return ASCENT_E_NODEVICE; }
+  std::lock_guard<std::mutex> lock(g_mu[device_id]);
+  HIPCHK(hipSetDevice(device_id));
+  hipStream_t stream = (hipStream_t)stream_;
+  const size_t nco = (size_t)4 * (coast_nodes + 1) * batch;
+  if (ptr_is_device) {
+    int rc = coast_run(p, (long)batch, final_state, coast_nodes, coast_traj, coast_tf, apsides, stream, g_err, sizeof g_err);
+    if (rc) return rc;
+    if (!stream) HIPCHK(hipStreamSynchronize(stream));
+    return ASCENT_OK;
+  }
+  DevBuf<ascent_params> bp;
+  DevBuf<double> bs, bc, bt, ba;
+  HIPCHK(bp.alloc(batch)); HIPCHK(bs.alloc((size_t)4 * batch)); HIPCHK(bc.alloc(nco)); HIPCHK(bt.alloc(batch)); HIPCHK(ba.alloc((size_t)2 * batch));
+  HIPCHK(hipMemcpyAsync(bp.d, p, batch * sizeof(ascent_params), hipMemcpyHostToDevice, stream));
+  HIPCHK(hipMemcpyAsync(bs.d, final_state, (size_t)4 * batch * sizeof(double), hipMemcpyHostToDevice, stream));
+  int rc = coast_run(bp.d, (long)batch, bs.d, coast_nodes, bc.d, bt.d, ba.d, stream, g_err, sizeof g_err);
+  if (rc) return rc;
+  HIPCHK(hipMemcpyAsync(coast_traj, bc.d, nco * sizeof(double), hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipMemcpyAsync(coast_tf, bt.d, batch * sizeof(double), hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipMemcpyAsync(apsides, ba.d, (size_t)2 * batch * sizeof(double), hipMemcpyDeviceToHost, stream));
+  HIPCHK(hipStreamSynchronize(stream));
   return ASCENT_OK;
 }
 

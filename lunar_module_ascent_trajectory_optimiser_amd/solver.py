@@ -19,17 +19,22 @@ def blob_rows(nt: int) -> int:
     return 21 * (nt - 1) + 10
 
 
-SCHEMES = {"backward_euler": 0, "trapezoid": 1}
+SCHEMES = {"backward_euler": 0, "trapezoid": 1, "hermite_simpson": 2}
+TERMINALS = {"reference": 0, "ellipse": 1}
 
 
 FORMULATIONS = {"current": 0, "v1": 1}
 
 
-def _opts(nt, max_iter, tol, warm_start, mu_init, scheme=0, formulation=0, coarse_nodes=0):
+def _opts(nt, max_iter, tol, warm_start, mu_init, scheme=0, formulation=0, coarse_nodes=0, terminal=0, path="auto"):
     scheme = SCHEMES.get(scheme, scheme)
     formulation = FORMULATIONS.get(formulation, formulation)
+    terminal = TERMINALS.get(terminal, terminal)
+    if path not in ("auto", "dense"):
+        raise ValueError('solver path must be "auto" or "dense"')
     return _lib.AscentOptsC(n_nodes=nt, scheme=int(scheme), max_iter=max_iter, warm_start=warm_start, tol=tol,
-                            mu_init=mu_init, formulation=int(formulation), coarse_nodes=int(coarse_nodes))
+                            mu_init=mu_init, formulation=int(formulation), coarse_nodes=int(coarse_nodes),
+                            terminal=int(terminal), solver_path=_lib.PATHS[path])
 
 
 def _ptr(a):
@@ -77,6 +82,11 @@ class BatchResult:
         return dict(periapsis_alt=a * (1 - e) - R0, apoapsis_alt=a * (1 + e) - R0, semi_major_axis=a, eccentricity=e,
                     flight_path_angle=np.arcsin(np.clip((X * VX + Y * VY) / (r * np.sqrt(v2)), -1, 1)))
 
+    def coast(self, coast_nodes: int = 200, device: int = 0) -> dict:
+        """The second phase: coast from every problem's burnout state to the apoapsis of its orbit, propagated on the
+        device (Kepler-exact; see coast_batch).  With terminal="ellipse" the arc ends at r_apo above the surface."""
+        return coast_batch(self.params, np.ascontiguousarray(self.traj[:4, -1, :]), coast_nodes, device)
+
     def outputs(self, i: int = 0) -> dict:
         """The quantities the reference prints/plots for problem i (Launch_Optimiser.py:178-202):
         physical t, x_pos (sign flipped as :200), y_pos (:201), theta in degrees (:202), mass, and
@@ -99,10 +109,15 @@ class BatchResult:
 
 def solve_batch(params, nt: int = 200, tol: float = 1e-9, max_iter: int = 300, guess: np.ndarray | None = None,
                 warm_start: int | None = None, mu_init: float = 0.0, device: int = 0, want_traj: bool = True,
-                want_blob: bool = False, scheme=0, formulation=0, coarse_nodes: int = 0) -> BatchResult:
+                want_blob: bool = False, scheme=0, formulation=0, coarse_nodes: int = 0, terminal=0,
+                path: str = "auto") -> BatchResult:
     """Solve a batch of ascent NLPs on one GPU.  params: AscentParams | list | (batch,16) array.
     guess: (21K+10, batch) blob, with warm_start 1 (primal only) or 2 (primal-dual).
-    scheme: 0 / "backward_euler" (the reference's NODES=2) or 1 / "trapezoid" (control held over the step).
+    scheme: 0 / "backward_euler" (the reference's NODES=2), 1 / "trapezoid" or 2 / "hermite_simpson" (both with the
+    control held over the step; scheme 2 runs on the dense-block solver path).
+    terminal: 0 / "reference" (Launch_Optimiser.py:72-78) or 1 / "ellipse" (the (r_peri, r_apo) ellipse proper: vis-viva
+    speed at its periapsis; `BatchResult.coast()` then ends at its apoapsis).
+    path: "auto" or "dense" (the dense-block path for any scheme).
     formulation: 0 / "current" or 1 / "v1" (the PDF appendix script: the angle is the MV; see include/ascent.h).
     coarse_nodes: nested iteration for cold starts (0 automatic, -1 single grid, > 0 explicit coarse grid);
     `iters` then counts the iterations of all grid levels."""
@@ -122,7 +137,7 @@ def solve_batch(params, nt: int = 200, tol: float = 1e-9, max_iter: int = 300, g
     tf = np.empty(B)
     status = np.empty(B, dtype=np.int32)
     iters = np.empty(B, dtype=np.int32)
-    o = _opts(nt, max_iter, tol, warm_start, mu_init, scheme, formulation, coarse_nodes)
+    o = _opts(nt, max_iter, tol, warm_start, mu_init, scheme, formulation, coarse_nodes, terminal, path)
     _lib.check(L.ascent_solve_batch(_ptr(P), B, C.byref(o), _ptr(guess), _ptr(traj), _ptr(tf), _ptr(status),
                                     _ptr(iters), _ptr(blob), device, None, 0))
     return BatchResult(P, nt, traj, tf, status, iters, blob, L.ascent_last_kernel_ms(device))
@@ -146,7 +161,7 @@ def eval_nodes(params, iterate: np.ndarray, nt: int = 200, device: int = 0, path
 
 
 def kkt_step(params, iterate: np.ndarray, mu, delta_w, nt: int = 200, device: int = 0, path="auto", scheme=0,
-             formulation=0):
+             formulation=0, terminal=0):
     """One Newton step of the barrier problem at `iterate` -> (step blob, inertia flags); `path` as in eval_nodes."""
     L = _lib.load()
     P = pack(params)
@@ -158,10 +173,41 @@ def kkt_step(params, iterate: np.ndarray, mu, delta_w, nt: int = 200, device: in
     dw = np.ascontiguousarray(np.broadcast_to(np.asarray(delta_w, dtype=np.float64), (B,)))
     step = np.empty_like(it)
     inertia = np.empty(B, dtype=np.int32)
-    o = _opts(nt, 0, 1.0, 0, 0.0, scheme, formulation)
+    o = _opts(nt, 0, 1.0, 0, 0.0, scheme, formulation, terminal=terminal)
     _lib.check(L.ascent_kkt_step_path(_ptr(P), B, C.byref(o), _ptr(it), _ptr(mu), _ptr(dw), _ptr(step), _ptr(inertia),
                                       device, _lib.PATHS[path]))
     return step, inertia
+
+
+def dense_records(params, iterate: np.ndarray, nt: int = 200, scheme=2, device: int = 0) -> np.ndarray:
+    """The dense stage records of the dense-block path at `iterate`: (batch, K, 6, 8, 8) -- grids d c_k/d z_{k-1}, d c_k/d z_k,
+    the three Hessian blocks of lambda_k'c_k and the vector grid (rows c_k, d c_k/du_k, d c_k/d tf, the two (z, tf) Hessian
+    columns); see ascent_dense_records in include/ascent.h."""
+    L = _lib.load()
+    P = pack(params)
+    B, K = P.shape[0], nt - 1
+    it = np.ascontiguousarray(iterate, dtype=np.float64)
+    if it.shape != (blob_rows(nt), B):
+        raise ValueError("iterate has the wrong shape")
+    rec = np.empty((B, K, 6, 8, 8))
+    o = _opts(nt, 0, 1.0, 0, 0.0, scheme)
+    _lib.check(L.ascent_dense_records(_ptr(P), B, C.byref(o), _ptr(it), _ptr(rec), device))
+    return rec
+
+
+def coast_batch(params, final_state: np.ndarray, coast_nodes: int = 200, device: int = 0) -> dict:
+    """Kepler-exact coast arc from every problem's burnout state (4, batch: scaled x, y, xdot, ydot) to the next apoapsis of
+    its orbit (ascent_coast_batch): dict(traj (4, coast_nodes+1, batch), tf (batch,) = duration / T_scale,
+    periapsis_alt, apoapsis_alt (m))."""
+    L = _lib.load()
+    P = pack(params)
+    B = P.shape[0]
+    fs = np.ascontiguousarray(final_state, dtype=np.float64)
+    if fs.shape != (4, B):
+        raise ValueError(f"final_state must have shape {(4, B)}")
+    traj = np.empty((4, coast_nodes + 1, B)); tf = np.empty(B); aps = np.empty((2, B))
+    _lib.check(L.ascent_coast_batch(_ptr(P), B, _ptr(fs), coast_nodes, _ptr(traj), _ptr(tf), _ptr(aps), device, None, 0))
+    return dict(traj=traj, tf=tf, periapsis_alt=aps[0], apoapsis_alt=aps[1])
 
 
 def solve_batch_torch(params_t, nt: int = 200, tol: float = 1e-9, max_iter: int = 300, guess_t=None,

@@ -385,7 +385,21 @@ class AscentNLP:
 # ----------------------------------------------------------------------------------
 # primal-dual interior point (restating Waechter & Biegler 2006 with an l1 merit line search)
 # ----------------------------------------------------------------------------------
-def solve_ip(nlp: AscentNLP, v0=None, tol=1e-9, max_iter=300, mu0=0.1, verbose=False):
+def _factor_with_inertia(Kmat, n, m):
+    """Sparse LU without row pivoting on a symmetric ordering (= an LDL' factorisation with a diagonal D): the signs of
+    U's diagonal are the inertia (Sylvester).  Returns (lu, ok) with ok = exactly n positive and m negative pivots."""
+    Kmat.eliminate_zeros()
+    lu = spla.splu(Kmat, permc_spec="MMD_AT_PLUS_A", diag_pivot_thresh=0.0, options=dict(SymmetricMode=True))
+    dU = lu.U.diagonal()
+    sym = np.array_equal(lu.perm_r, lu.perm_c)
+    return lu, bool(sym and np.all(np.isfinite(dU)) and (dU > 0).sum() == n and (dU < 0).sum() == m)
+
+
+def solve_ip(nlp: AscentNLP, v0=None, tol=1e-9, max_iter=300, mu0=0.1, verbose=False, inertia="curvature"):
+    """inertia: "curvature" = accept a step when dx'(W+Sigma+dw)dx > 0 along it (the test this oracle has always used: cheap,
+    sufficient on the single-phase problems); "exact" = IPOPT's rule, the KKT matrix must have exactly n positive and m
+    negative eigenvalues, read off an LDL' factorisation (needed on the burn-coast problems, whose Newton systems are
+    indefinite in directions a single curvature sample does not see)."""
     n, m = nlp.n, nlp.m
     lb, ub = nlp.lb, nlp.ub
     hasL, hasU = np.isfinite(lb), np.isfinite(ub)
@@ -444,22 +458,34 @@ def solve_ip(nlp: AscentNLP, v0=None, tol=1e-9, max_iter=300, mu0=0.1, verbose=F
         dw = 0.0
         while True:
             Hm = Wm + sp.diags(Sig + dw)
-            Kmat = sp.bmat([[Hm, J.T], [J, None]], format="csc")
+            # (exact inertia: a 1e-10 dual regularisation makes the matrix quasi-definite, so that the unpivoted LDL' exists)
+            Kmat = sp.bmat([[Hm, J.T], [J, -1e-10 * sp.eye(m) if inertia == "exact" else None]], format="csc")
             try:
-                sol = spla.splu(Kmat).solve(rhs)
-                dx, dlam = sol[:n], sol[n:]
-                curv = dx @ (Hm @ dx)
-                ok = np.all(np.isfinite(sol)) and curv >= 1e-11 * (dx @ dx)
+                if inertia == "exact":
+                    lu, ok = _factor_with_inertia(Kmat, n, m)
+                    sol = lu.solve(rhs)
+                    ok = ok and bool(np.all(np.isfinite(sol)))
+                    dx, dlam = sol[:n], sol[n:]
+                    curv = dx @ (Hm @ dx)
+                else:
+                    sol = spla.splu(Kmat).solve(rhs)
+                    dx, dlam = sol[:n], sol[n:]
+                    curv = dx @ (Hm @ dx)
+                    ok = np.all(np.isfinite(sol)) and curv >= 1e-11 * (dx @ dx)
             except RuntimeError:
                 ok = False
             if ok:
                 break
-            dw = 1e-4 if dw == 0 else (max(1e-4, dw_last / 3) if dw < 0 else dw * 8)
+            if inertia == "exact":       # IPOPT's Algorithm IC: restart from a third of the last successful value, floor 1e-20
+                dw = (max(1e-20, dw_last / 3.0) if dw_last > 0 else 1e-4) if dw == 0 else dw * (8.0 if dw_last > 0 else 100.0)
+            else:
+                dw = 1e-4 if dw == 0 else (max(1e-4, dw_last / 3) if dw < 0 else dw * 8)
             info["reg"] += 1
             if dw > 1e10:
                 info.update(status="reg_failed")
                 return v, lam, info
-        dw_last = dw
+        if inertia != "exact" or dw > 0:
+            dw_last = dw
         dzL = np.where(hasL, mu / dL - zL - zL / dL * dx, 0)
         dzU = np.where(hasU, mu / dU - zU + zU / dU * dx, 0)
         tau = max(0.99, 1 - mu)

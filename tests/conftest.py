@@ -58,7 +58,11 @@ def generic_lu_newton_step(P, nt, blob, mu, dw, scheme=0):
     import scipy.sparse.linalg as spla
     from oracle.ascent_numpy import AscentNLP
     K = nt - 1
-    nlp = AscentNLP(P, nt, 0, scheme=scheme)
+    if scheme == 2:      # Hermite-Simpson: the generalised oracle (sympy-generated derivatives), same variable layout
+        from oracle.ascent_general import GeneralNLP
+        nlp = GeneralNLP(P, ((K, "burn"),), 2)
+    else:
+        nlp = AscentNLP(P, nt, 0, scheme=scheme)
     v = np.zeros(nlp.n); lam = np.zeros(nlp.m); zL = np.zeros(nlp.n); zU = np.zeros(nlp.n)
     Wk = v[:8 * K].reshape(K, 8)
     Wk[:, :7] = blob[:7 * K].reshape(K, 7); Wk[:, 7] = blob[7 * K:8 * K]

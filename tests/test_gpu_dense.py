@@ -1,0 +1,238 @@
+"""GPU parity tests of the dense-block solver path (csrc/ascent_dense.hip: d_eval -> d_newton, one wavefront per NLP):
+Hermite-Simpson (scheme 2), the ellipse-proper terminal constraints, the coast arc -- BASELINE.json configs[4] -- and, as
+a cross-check of two independent HIP implementations, schemes 0/1 through the dense path against the hand-tuned
+kernels.  The checker for scheme 2 is oracle/ascent_general.py (sympy-generated derivatives, generic sparse LU); the
+HIP side derives the same blocks by hand."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import lunar_module_ascent_trajectory_optimiser_amd as A
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(__file__)
+X, Y, VX, VY, AN, W, MS = range(7)
+
+
+def _interior_blobs(coracle, S, nt, scheme):
+    """Strictly interior primal-dual iterates (a few oracle iterations of a scheme the C oracle has, multipliers perturbed)."""
+    blobs = []
+    for b, row in enumerate(S):
+        rng = np.random.default_rng(300 + b)
+        r = coracle.solve_batch(row[None], nt, 3 + b % 4, 1e-9, want_blob=True, coarse_nodes=-1, scheme=min(scheme, 1))
+        blob = r["blob"][0].copy()
+        K = nt - 1
+        blob[8 * K:15 * K] += 0.05 * rng.standard_normal(7 * K)
+        blob[15 * K:21 * K] *= rng.uniform(0.7, 1.3, 6 * K)
+        blobs.append(blob)
+    coracle.set_scheme(0)
+    return np.stack(blobs, axis=1)
+
+
+@pytest.mark.parametrize("scheme", [0, 1, 2])
+def test_dense_stage_records_match_symbolic_derivatives(coracle, scheme):
+    """d_eval's dense blocks -- d c_k/d z_{k-1}, d c_k/d z_k, the three Hessian blocks of lambda_k'c_k, the theta and
+    control columns -- against the Jacobian and Hessian sympy generates from the one-line symbolic step defect."""
+    from conftest import params_of_row
+    from oracle.ascent_general import GeneralNLP
+    nt = 24
+    K = nt - 1
+    S = A.sweep_isp_drymass(2, 1)
+    blobs = _interior_blobs(coracle, S, nt, scheme)
+    rec = A.dense_records(S, blobs, nt, scheme=scheme)
+    for b in range(len(S)):
+        blob = blobs[:, b]
+        nlp = GeneralNLP(params_of_row(S[b]), ((K, "burn"),), scheme)
+        v = np.zeros(nlp.n); lam = np.zeros(nlp.m)
+        v[:8 * K].reshape(K, 8)[:, :7] = blob[:7 * K].reshape(K, 7)
+        v[:8 * K].reshape(K, 8)[:, 7] = blob[7 * K:8 * K]
+        lam[:7 * K] = blob[8 * K:15 * K]
+        v[nlp.itf] = blob[21 * K]
+        c, J, H = nlp._steps(v, lam)
+        for k in range(K):
+            g = rec[b, k]
+            scale = max(1.0, np.abs(H[k]).max())
+            assert np.abs(g[5, 0, :7] - c[k]).max() < 1e-13
+            assert np.abs(g[1, :7, :7] - J[k][:, 7:14]).max() < 1e-12
+            if k:
+                assert np.abs(g[0, :7, :7] - J[k][:, 0:7]).max() < 1e-12
+                assert np.abs(g[2, :7, :7] - H[k][0:7, 0:7]).max() < 1e-11 * scale
+                assert np.abs(g[3, :7, :7] - H[k][0:7, 7:14]).max() < 1e-11 * scale
+                assert np.abs(g[5, 3, :7] - H[k][0:7, 15]).max() < 1e-11 * scale
+            assert np.abs(g[4, :7, :7] - H[k][7:14, 7:14]).max() < 1e-11 * scale
+            assert np.abs(g[5, 1, :7] - J[k][:, 14]).max() < 1e-13
+            assert np.abs(g[5, 2, :7] - J[k][:, 15]).max() < 1e-12 * max(1.0, np.abs(J[k][:, 15]).max())
+            assert np.abs(g[5, 4, :7] - H[k][7:14, 15]).max() < 1e-11 * scale
+            assert g[1, 7, 7] == 1.0 and np.abs(g[0, 7]).max() == 0.0          # the padding slot
+
+
+@pytest.mark.parametrize("scheme", [0, 1, 2])
+def test_dense_newton_step_matches_generic_lu(coracle, scheme):
+    """One Newton step of the barrier problem through d_eval -> d_newton (dense Riccati recursion with two border
+    columns, Gauss-Jordan step-Jacobian inverse, multiplier step from the forward pass) against the generic sparse-LU
+    solve of the full KKT matrix -- for scheme 2 assembled from the sympy-generated derivatives -- and, for schemes 0/1,
+    against the C oracle's stage-wise step as well; with and without primal regularisation."""
+    from conftest import generic_lu_newton_step, params_of_row
+    nt = 40
+    K = nt - 1
+    S = A.sweep_isp_drymass(2, 2)
+    blobs = _interior_blobs(coracle, S, nt, scheme)
+    mu = np.array([0.1, 0.02, 1e-3, 0.05]); dw = np.array([0.0, 1e-4, 1e-2, 1.0])
+    step, inertia = A.kkt_step(S, blobs, mu, dw, nt, path="dense", scheme=scheme)
+    n_ok = 0
+    for b in range(len(S)):
+        blob = np.ascontiguousarray(blobs[:, b])
+        if scheme < 2:
+            rc, ref = coracle.newton_step(S[b], nt, blob, mu[b], dw[b], scheme=scheme)
+            coracle.set_scheme(0)
+            assert rc == inertia[b]
+            if rc == 0:
+                assert np.abs(step[:, b] - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+        if inertia[b]:
+            continue
+        n_ok += 1
+        lu, _, _, _ = generic_lu_newton_step(params_of_row(S[b]), nt, blob, mu[b], dw[b], scheme)
+        for lo, hi in ((0, 8 * K), (8 * K, 15 * K), (15 * K, 21 * K), (21 * K, 21 * K + 10)):
+            assert np.abs(step[lo:hi, b] - lu[lo:hi]).max() <= 1e-8 * max(1.0, np.abs(lu[lo:hi]).max())
+    assert n_ok >= 3
+
+
+def test_dense_path_equals_hand_tuned_path_on_schemes_0_and_1(coracle):
+    """Two independent HIP implementations of the same interior point: the hand-tuned sparse kernels (closed-form step
+    Jacobian inverse, packed congruences) and the dense-block path.  Same iteration counts, t_f to rounding, both the oracle's."""
+    S = A.sweep_isp_drymass(5, 4)
+    for scheme in (0, 1):
+        d = A.solve_batch(S, 200, tol=1e-9, scheme=scheme, path="dense")
+        h = A.solve_batch(S, 200, tol=1e-9, scheme=scheme)
+        ref = coracle.solve_batch(S, 200, 300, 1e-9, scheme=scheme)
+        coracle.set_scheme(0)
+        assert np.all(d.status == 0) and np.all(h.status == 0)
+        assert np.array_equal(d.iters, h.iters) and np.array_equal(d.iters, ref["iters"])
+        assert np.abs(d.tf - h.tf).max() <= 1e-11 and np.abs(d.tf - ref["tf"]).max() <= 1e-9
+        for f in (0, 1, 2, 3, 6, 9):
+            assert np.abs(d.traj[f] - h.traj[f]).max() <= 1e-6 * max(1.0, np.abs(h.traj[f]).max())
+
+
+def _fixtures():
+    fx = json.load(open(os.path.join(HERE, "golden", "hs_fixtures.json")))
+    return {(c["nt"], c["scheme"], c["terminal"]): c for c in fx["cases"]}
+
+
+def test_hermite_simpson_matches_independent_fixtures():
+    """scheme = 2 against tests/golden/hs_fixtures.json (generalised numpy oracle; made by scripts/make_hs_fixtures.py):
+    t_f to 1e-9, final state to 1e-6, sampled trajectory to 1e-6 (angle 1e-5) -- at N = 50, 200, 400 with the reference's terminal
+    constraints, at N = 200 with the ellipse-proper ones (and at N = 2000 when that fixture has been generated)."""
+    by = _fixtures()
+    for (nt, scheme, terminal), c in sorted(by.items()):
+        r = A.solve_batch(A.AscentParams(), nt, tol=1e-10, scheme=scheme, terminal="ellipse" if terminal == "periapsis" else "reference",
+                          max_iter=500)
+        assert r.status[0] == 0
+        assert abs(r.tf[0] - c["tf"]) <= 1e-9, (nt, scheme, terminal, r.tf[0], c["tf"])
+        fs = np.array([r.traj[f][-1, 0] for f in (0, 1, 2, 3, 6, 7, 9)])
+        assert np.abs(fs - np.array(c["final_state"])).max() <= 1e-6
+        stride = max(1, (nt - 1) // 20)
+        # (the angle around the junction of the saturated and the singular arc is only weakly determined by a KKT point)
+        for name, key, tol in (("x", "x", 1e-6), ("y", "y", 1e-6), ("angle", "angle", 1e-5)):
+            assert np.abs(r.field(name)[::stride, 0] - np.array(c[key])).max() <= tol
+        o = r.orbit()
+        assert abs(o["periapsis_alt"][0] - c["orbit_periapsis_alt_m"]) < 0.01 and abs(o["apoapsis_alt"][0] - c["orbit_apoapsis_alt_m"]) < 0.01
+
+
+def test_hermite_simpson_sweep_and_mesh_refinement():
+    """A sweep through scheme 2: every NLP converges; HS at N = 200 is within 0.01 s of HS at N = 800 on every problem (the
+    backward-Euler answers of the same problems are 1.2 s away from their own limit), and the limit agrees with the
+    trapezoid answers at N = 800 (the two second-order-or-better schemes of this repository, independent code paths)."""
+    S = A.sweep_isp_drymass(4, 4)
+    h2 = A.solve_batch(S, 200, tol=1e-9, scheme=2)
+    h8 = A.solve_batch(S, 800, tol=1e-9, scheme=2, max_iter=500)
+    t8 = A.solve_batch(S, 800, tol=1e-9, scheme=1, max_iter=500)
+    assert np.all(h2.status == 0) and np.all(h8.status == 0) and np.all(t8.status == 0)
+    assert np.abs(h2.final_time() - h8.final_time()).max() < 0.01
+    assert np.abs(h8.final_time() - t8.final_time()).max() < 0.01
+    be = A.solve_batch(S, 200, tol=1e-9)
+    assert np.all(h8.final_time() - be.final_time() > 1.0)
+
+
+def test_config5_high_resolution_burn_then_coast():
+    """BASELINE.json configs[4]: N = 2000 Hermite-Simpson, angular-acceleration bound active, burn to the 17.7 x 88.6 km
+    ellipse proper (README.md:7) followed by the coast arc to its apoapsis, propagated on the device.  Size-independent
+    properties on a 64-NLP sweep: every problem converges; the burnout orbit is the target ellipse to 1 m for every
+    problem (BatchResult.orbit(): host-side closed form; coast(): the device's own elements); the coast ends at r_apo with
+    r.v = 0; its duration is half the orbital period; the bang-bang part of the control sits on its bound."""
+    S = np.vstack([A.AscentParams().as_row()[None], A.sweep_isp_drymass(9, 7)])
+    r = A.solve_batch(S, 2000, tol=1e-9, scheme="hermite_simpson", terminal="ellipse", max_iter=500)
+    assert np.all(r.status == 0)
+    o = r.orbit()
+    assert np.abs(o["periapsis_alt"] - 17703.0).max() < 1.0 and np.abs(o["apoapsis_alt"] - 88615.0).max() < 1.0
+    assert np.abs(o["flight_path_angle"]).max() < 1e-8
+    c = r.coast(coast_nodes=2000)
+    assert np.abs(c["periapsis_alt"] - 17703.0).max() < 1.0 and np.abs(c["apoapsis_alt"] - 88615.0).max() < 1.0
+    Sx, R0, GM = 17703.0, 1738100.0, 6.674e-11 * 7.346e22
+    Xe, Ye = c["traj"][0, -1] * Sx, c["traj"][1, -1] * Sx + R0
+    VXe, VYe = c["traj"][2, -1] * Sx, c["traj"][3, -1] * Sx
+    assert np.abs(np.hypot(Xe, Ye) - R0 - 88615.0).max() < 1.0
+    assert np.abs(Xe * VXe + Ye * VYe).max() / (np.hypot(Xe, Ye) * np.hypot(VXe, VYe)).min() < 1e-9
+    a = R0 + 0.5 * (17703.0 + 88615.0)
+    assert np.abs(c["tf"] * 470.0 - np.pi * np.sqrt(a ** 3 / GM)).max() < 0.05
+    # first node of the coast = last node of the burn; energy and angular momentum constant along the arc
+    assert np.abs(c["traj"][:, 0, :] - r.traj[:4, -1, :]).max() < 1e-10
+    X_, Y_ = c["traj"][0] * Sx, c["traj"][1] * Sx + R0
+    VX_, VY_ = c["traj"][2] * Sx, c["traj"][3] * Sx
+    en = 0.5 * (VX_ ** 2 + VY_ ** 2) - GM / np.hypot(X_, Y_)
+    hm = X_ * VY_ - Y_ * VX_
+    assert np.abs(en / en[0] - 1).max() < 1e-10 and np.abs(hm / hm[0] - 1).max() < 1e-10
+    u = r.field("angledoubledot")
+    assert np.all(np.abs(u) <= 1 + 1e-9) and (np.abs(u[:, 0]) > 0.999).sum() >= 400     # 47 of 199 steps at N = 200
+    # mesh refinement: the same problems at N = 200 land within 0.01 s
+    r2 = A.solve_batch(S[:8], 200, tol=1e-9, scheme=2, terminal="ellipse")
+    assert np.abs(r2.final_time() - r.final_time()[:8]).max() < 0.01
+    by = _fixtures()
+    if (2000, 2, "periapsis") in by:
+        assert abs(r.tf[0] - by[(2000, 2, "periapsis")]["tf"]) <= 1e-9
+
+
+def test_ellipse_terminal_through_the_hand_tuned_kernels(coracle):
+    """ascent_opts.terminal = 1 is available on every path (the solvers run on a parameter copy whose mean radius
+    reproduces the vis-viva speed): backward Euler through the 16-lane split kernels against the C oracle run on
+    parameters transformed the same way on the host, and against the generalised numpy oracle's fixture."""
+    S = A.sweep_isp_drymass(3, 3)
+    r = A.solve_batch(S, 200, tol=1e-9, terminal="ellipse")
+    assert np.all(r.status == 0)
+    f = A.PARAM_FIELDS
+    T = S.copy()
+    rp, ra = T[:, f.index("R0")] + T[:, f.index("r_peri")], T[:, f.index("R0")] + T[:, f.index("r_apo")]
+    T[:, f.index("r_apo")] = 2.0 * (1.0 / (2.0 / rp - 2.0 / (rp + ra)) - T[:, f.index("R0")]) - T[:, f.index("r_peri")]
+    ref = coracle.solve_batch(T, 200, 300, 1e-9)
+    assert np.abs(r.tf - ref["tf"]).max() <= 1e-9 and np.array_equal(r.iters, ref["iters"])
+    o = r.orbit()
+    assert np.abs(o["periapsis_alt"] - 17703.0).max() < 0.01 and np.abs(o["apoapsis_alt"] - 88615.0).max() < 0.01
+    n = A.solve_batch(A.AscentParams(), 200, tol=1e-10, terminal="ellipse")
+    assert abs(n.tf[0] - _fixtures()[(200, 0, "periapsis")]["tf"]) <= 1e-9
+
+
+def test_coast_arc_against_the_closed_form():
+    """ascent_coast_batch on synthetic states: an orbit given by its elements, a start at an arbitrary true anomaly."""
+    P = A.AscentParams()
+    GM, R0, Sx = P.G * P.M, P.R0, P.r_peri
+    a, e = R0 + 60e3, 0.03
+    states, expect = [], []
+    for nu0 in (0.0, 0.7, 2.5, 3.6):
+        p_ = a * (1 - e * e)
+        r0 = p_ / (1 + e * np.cos(nu0))
+        vr, vt = np.sqrt(GM / p_) * e * np.sin(nu0), np.sqrt(GM / p_) * (1 + e * np.cos(nu0))
+        ph = 0.2 + nu0                                   # polar angle from +y towards -x, as the ascent flies
+        Xp, Yp = -r0 * np.sin(ph), r0 * np.cos(ph)
+        VXp, VYp = -vr * np.sin(ph) - vt * np.cos(ph), vr * np.cos(ph) - vt * np.sin(ph)
+        states.append([Xp / Sx, (Yp - R0) / Sx, VXp / Sx, VYp / Sx])
+        E0 = 2 * np.arctan2(np.sqrt(1 - e) * np.sin(nu0 / 2), np.sqrt(1 + e) * np.cos(nu0 / 2))
+        M0 = (E0 - e * np.sin(E0)) % (2 * np.pi)
+        expect.append(((np.pi - M0) % (2 * np.pi)) / np.sqrt(GM / a ** 3))
+    st = np.ascontiguousarray(np.array(states).T)
+    c = A.coast_batch(np.repeat(P.as_row()[None], 4, 0), st, coast_nodes=64)
+    assert np.abs(c["tf"] * P.T_scale - np.array(expect)).max() < 1e-6
+    assert np.abs(c["apoapsis_alt"] - (a * (1 + e) - R0)).max() < 1e-5 and np.abs(c["periapsis_alt"] - (a * (1 - e) - R0)).max() < 1e-5
+    Xe, Ye = c["traj"][0, -1] * Sx, c["traj"][1, -1] * Sx + R0
+    assert np.abs(np.hypot(Xe, Ye) - a * (1 + e)).max() < 1e-4
+    assert np.abs(c["traj"][:, 0, :] - st).max() < 1e-9
