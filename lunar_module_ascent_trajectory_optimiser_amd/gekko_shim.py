@@ -153,7 +153,10 @@ class _Options:
     """m.options: any attribute may be set; the ones that matter are checked at solve()."""
     def __init__(self):
         self.__dict__.update(NODES=2, SOLVER=3, IMODE=6, MAX_ITER=300, MV_TYPE=0, OTOL=1e-6, RTOL=1e-6,
-                             DIAGLEVEL=0, COLDSTART=0)
+                             DIAGLEVEL=0, COLDSTART=0,
+                             # extensions of this front end (not GEKKO options; real GEKKO ignores unknown attributes):
+                             ASCENT_SCHEME=0,      # 0 = NODES=2 backward Euler (the reference), 1 = trapezoid, 2 = Hermite-Simpson
+                             ASCENT_TERMINAL=0)    # 0 = the script's terminal speed (:72-78), 1 = the (r_peri, r_apo) ellipse proper
 
 
 # ----------------------------------------------------------------------------------------------
@@ -243,7 +246,11 @@ class GEKKO:
         if int(o.IMODE) != 6:
             raise ModelNotRecognised("only IMODE=6 (simultaneous dynamic optimisation) is supported")
         if int(o.NODES) != 2:
-            raise ModelNotRecognised("only NODES=2 (two-point collocation = backward Euler) is supported in this release")
+            raise ModelNotRecognised("only NODES=2 (two-point collocation = backward Euler, the reference's setting) is mapped; APMonitor's "
+                                     "NODES>=3 Radau collocation is not implemented -- m.options.ASCENT_SCHEME = 1 | 2 selects the "
+                                     "trapezoid / Hermite-Simpson transcriptions this library offers instead")
+        if int(getattr(o, "ASCENT_SCHEME", 0)) not in (0, 1, 2) or int(getattr(o, "ASCENT_TERMINAL", 0)) not in (0, 1):
+            raise ModelNotRecognised("ASCENT_SCHEME must be 0, 1 or 2 and ASCENT_TERMINAL 0 or 1")
         nt = len(self.time)
         if nt < 3 or not np.allclose(self.time, np.linspace(0.0, 1.0, nt)):
             raise ModelNotRecognised("m.time must be np.linspace(0, 1, nt)")
@@ -379,12 +386,34 @@ class GEKKO:
         if solver is None:
             from .solver import solve_batch as solver
         max_iter = int(min(max(int(self.options.MAX_ITER), 1), 3000))
-        res = solver(P, nt=nt, tol=1e-9, max_iter=max_iter, formulation=self._formulation)
+        # OTOL / RTOL (Launch_Optimiser.py:31-32) are honoured as an upper bound on the KKT error -- but never looser than 1e-9:
+        # IPOPT's 1e-3 is a tolerance on ITS scaled optimality measure, and the reference's answer is compared at 1e-4, which
+        # this solver's unscaled KKT error only guarantees from about 1e-8 down (at 1e-3 it stops 1.4 s early).
+        tol = max(1e-12, min(float(self.options.OTOL), float(self.options.RTOL), 1e-9))
+        scheme, terminal = int(getattr(self.options, "ASCENT_SCHEME", 0)), int(getattr(self.options, "ASCENT_TERMINAL", 0))
+        extra = {}
+        if scheme:
+            extra["scheme"] = scheme
+        if terminal:
+            extra["terminal"] = terminal
+        res = solver(P, nt=nt, tol=tol, max_iter=max_iter, formulation=self._formulation, **extra)
         self.result = res
         ok = int(res.status[0]) == 0
+        dcost = float(P.dcost)
+        if dcost and not getattr(GEKKO, "_dcost_warned", False):
+            GEKKO._dcost_warned = True
+            import warnings
+            warnings.warn(f"MV DCOST = {dcost:g} (Launch_Optimiser.py:99) is NOT applied by the HIP solver: measured with the l1 "
+                          "movement penalty in the CPU restatement, it shifts the nominal t_f by +1.5e-3 s (3.5e-6 relative; the "
+                          "parity bar is 1e-4) -- see DESIGN.md", stacklevel=2)
         if disp:
+            names = {0: "backward Euler (NODES=2)", 1: "trapezoid (ASCENT_SCHEME=1)", 2: "Hermite-Simpson (ASCENT_SCHEME=2)"}
             print(" ----------------------------------------------------------------")
-            print(" libascent (MI355X) interior point: %d node ascent NLP, backward Euler (NODES=2)" % nt)
+            print(" libascent (MI355X) interior point: %d node ascent NLP, %s" % (nt, names[scheme]))
+            print(" KKT tolerance %.1e (OTOL %.1e, RTOL %.1e: honoured as upper bounds, never looser than 1e-9)"
+                  % (tol, float(self.options.OTOL), float(self.options.RTOL)))
+            if dcost:
+                print(" MV DCOST %.1e: not applied (measured effect on t_f: +1.5e-3 s, see DESIGN.md)" % dcost)
             print(" iterations: %d   status: %s   objective tf: %.12g" % (int(res.iters[0]), "converged" if ok else f"FAILED ({int(res.status[0])})", float(res.tf[0])))
             print(" ----------------------------------------------------------------")
         if not ok:

@@ -25,8 +25,8 @@ def _oracle_solver(P, nt, tol, max_iter, formulation=0, **kw):
     from lunar_module_ascent_trajectory_optimiser_amd.params import pack
     from lunar_module_ascent_trajectory_optimiser_amd.solver import BatchResult
     P = pack(P)
-    r = c_oracle.solve_batch(P, nt, max_iter, tol, formulation=formulation)
-    c_oracle.set_formulation(0)
+    r = c_oracle.solve_batch(P, nt, max_iter, tol, formulation=formulation, scheme=kw.get("scheme", 0))
+    c_oracle.set_formulation(0); c_oracle.set_scheme(0)
     return BatchResult(P, nt, np.ascontiguousarray(np.moveaxis(r["traj"], 0, 2)), r["tf"], r["status"], r["iters"], None, 0.0)
 
 
@@ -195,3 +195,52 @@ def test_example_end_to_end_on_gpu(golden):
     assert abs(ft - golden["current"]["final_time"]) <= 1e-4 * golden["current"]["final_time"]
     assert "libascent (MI355X)" in buf.getvalue() and m.options.ITERATIONS > 5
     assert abs(3 * v["angle"].value[-1] * 180 / np.pi - golden["qualitative"]["angle_final_deg"]) < 0.2
+
+
+def test_solver_options_of_the_script_are_honoured(golden):
+    """m.options.OTOL / RTOL (Launch_Optimiser.py:31-32) bound the KKT tolerance from above but never loosen it beyond 1e-9 (the
+    banner says so); DCOST (:99) is reported as not applied; NODES other than 2 is refused with a pointer to the
+    ASCENT_SCHEME extension, which reaches the trapezoid scheme through the front door."""
+    import warnings
+    from lunar_module_ascent_trajectory_optimiser_amd.gekko_shim import GEKKO, ModelNotRecognised
+    seen = {}
+
+    def spy(P, nt, tol, max_iter, formulation=0, **kw):
+        seen.update(tol=tol, kw=kw)
+        return _oracle_solver(P, nt, tol, max_iter, formulation, **kw)
+
+    ex = _example()
+    GEKKO._dcost_warned = False
+    m, v, _ = ex.build(nt=60, solver=spy)
+    m.options.OTOL = m.options.RTOL = 1e-3                       # the reference's values
+    buf = io.StringIO()
+    with redirect_stdout(buf), warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m.solve(disp=True)
+    assert seen["tol"] == 1e-9 and "never looser than 1e-9" in buf.getvalue()
+    assert any("DCOST" in str(x.message) for x in w) and "DCOST 1.0e-05: not applied" in buf.getvalue()
+    m.options.OTOL = 1e-11
+    m.solve(disp=False)
+    assert seen["tol"] == 1e-11
+    t_be = v["x"].value[-1]
+    m.options.OTOL = 1e-6
+    m.options.ASCENT_SCHEME = 1
+    m.solve(disp=False)
+    assert seen["kw"].get("scheme") == 1 and v["x"].value[-1] != t_be
+    m.options.NODES = 3
+    with pytest.raises(ModelNotRecognised, match="ASCENT_SCHEME"):
+        m.solve(disp=False)
+
+
+@pytest.mark.gpu
+def test_hermite_simpson_and_ellipse_through_the_front_door():
+    """ASCENT_SCHEME = 2 / ASCENT_TERMINAL = 1 through the GEKKO-style surface on the HIP path: the high-order answer of the
+    reference's problem (435.227 s at 200 nodes) and the insertion into the 17.7 x 88.6 km ellipse proper (440.844 s)."""
+    ex = _example()
+    m, v, _ = ex.build()
+    m.options.ASCENT_SCHEME = 2
+    m.solve(disp=False)
+    assert abs(m.options.OBJFCNVAL * 470.0 - 435.226762) < 1e-4
+    m.options.ASCENT_TERMINAL = 1
+    m.solve(disp=False)
+    assert abs(m.options.OBJFCNVAL * 470.0 - 440.844369) < 1e-4
