@@ -187,6 +187,21 @@ int ascent_coast_batch(const ascent_params *p, int64_t batch, const double *fina
                        double *coast_traj, double *coast_tf, double *apsides, int device_id,
                        void *hip_stream_or_null, int ptr_is_device);
 
+/* Generic bordered block-tridiagonal solve (parity surface of the linear algebra):
+ *     [ T   B ] [x]   [r]        T: n_nodes x n_nodes blocks of size bs (<= 16): diag[i] on the diagonal, lower[i] = block
+ *     [ B'  d ] [y] = [s]           (i, i-1) (lower[0] ignored), upper[i] = block (i, i+1) (upper[n-1] ignored);
+ *                                B: nb border columns (1 + nb <= 16), d: nb x nb (border_diag, row-major).
+ * Layouts (host pointers, row-major, system index slowest): diag / lower / upper [batch][n_nodes][bs][bs],
+ * border [batch][n_nodes][bs][nb], border_diag [batch][nb][nb], rhs and sol [batch][n_nodes*bs + nb].
+ * algo 0: block elimination serial in the node index, one wavefront per system; algo 1: parallel cyclic reduction over
+ * the nodes (one wavefront per node, log2(n_nodes) levels).  Blocks are padded to 16x16 and multiplied with
+ * v_mfma_f64_16x16x4_f64; no pivoting inside blocks (returns ASCENT_E_ARG "singular pivot" if one vanishes); the
+ * border is closed by a Schur complement on the host.  The interior-point solver does not call this (it uses a
+ * Riccati recursion in the 7x7 value function); ascent_last_kernel_ms reports the device time of the solve. */
+int ascent_kkt_solve(int64_t batch, int32_t n_nodes, int32_t bs, int32_t nb, const double *diag, const double *lower,
+                     const double *upper, const double *border, const double *border_diag, const double *rhs,
+                     double *sol, int device_id, int algo);
+
 /* Device time (ms) of the solve kernel of the most recent ascent_solve_batch on this device,
  * measured with HIP events recorded on the launch stream around the kernel; waits for that
  * kernel to finish; < 0 if there was none. */

@@ -32,7 +32,7 @@ class AscentOptsC(C.Structure):
 
 SYMBOLS = ("ascent_version", "ascent_device_count", "ascent_strerror", "ascent_solve_batch",
            "ascent_eval_nodes", "ascent_kkt_step", "ascent_eval_nodes_path", "ascent_kkt_step_path",
-           "ascent_dense_records", "ascent_coast_batch", "ascent_last_kernel_ms")
+           "ascent_dense_records", "ascent_coast_batch", "ascent_kkt_solve", "ascent_last_kernel_ms")
 PATHS = {"auto": 0, "fused": 1, "split_lane": 2, "split_wide": 3, "dense": 4}     # enum ascent_path
 
 _lib = None
@@ -76,6 +76,8 @@ def load():
     L.ascent_kkt_step_path.argtypes = L.ascent_kkt_step.argtypes + [C.c_int]
     L.ascent_dense_records.restype = C.c_int
     L.ascent_dense_records.argtypes = [C.c_void_p, C.c_int64, C.POINTER(AscentOptsC), C.c_void_p, C.c_void_p, C.c_int]
+    L.ascent_kkt_solve.restype = C.c_int
+    L.ascent_kkt_solve.argtypes = [C.c_int64, C.c_int32, C.c_int32, C.c_int32] + [C.c_void_p] * 7 + [C.c_int, C.c_int]
     L.ascent_coast_batch.restype = C.c_int
     L.ascent_coast_batch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                      C.c_int, C.c_void_p, C.c_int]

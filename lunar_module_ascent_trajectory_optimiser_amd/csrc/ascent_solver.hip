@@ -25,12 +25,15 @@
 #include <cstdlib>
 #include <cstring>
 #include <mutex>
+#include <vector>
+#include <cmath>
 
 #include "ascent.h"
 #include "ascent_device.hpp"
 #include "ascent_tile.hpp"
 #include "ascent_pipeline.hpp"
 #include "ascent_dense.hpp"
+#include "ascent_blocktri.hpp"
 
 using namespace ascent;
 
@@ -1351,6 +1354,81 @@ int ascent_coast_batch(const ascent_params *p, int64_t batch, const double *fina
 int ascent_kkt_step(const ascent_params *p, int64_t batch, const ascent_opts *o, const double *iterate,
                     const double *mu, const double *delta_w, double *step, int32_t *inertia_out, int device_id) {
   return ascent_kkt_step_path(p, batch, o, iterate, mu, delta_w, step, inertia_out, device_id, ASCENT_PATH_AUTO);
+}
+
+int ascent_kkt_solve(int64_t batch, int32_t n, int32_t bs, int32_t nb, const double *diag, const double *lower,
+                     const double *upper, const double *border, const double *border_diag, const double *rhs,
+                     double *sol, int device_id, int algo) {
+  if (batch <= 0 || n < 1 || n > 65535 || bs < 1 || bs > 16 || nb < 0 || nb > 15 || (algo != 0 && algo != 1)) {
+    snprintf(g_err, sizeof g_err, "ascent_kkt_solve: need batch > 0, 1 <= n_nodes <= 65535, 1 <= bs <= 16, 0 <= nb <= 15, algo 0 | 1");
+    return ASCENT_E_ARG;
+  }
+  if (!diag || !lower || !upper || !rhs || !sol || (nb && (!border || !border_diag))) { snprintf(g_err, sizeof g_err, "null pointer"); return ASCENT_E_ARG; }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) { snprintf(g_err, sizeof g_err, "no HIP device available"); return ASCENT_E_NODEVICE; }
+  if (device_id < 0 || device_id >= ndev || device_id >= MAX_DEV) { snprintf(g_err, sizeof g_err, "device %d of %d", device_id, ndev); return ASCENT_E_NODEVICE; }
+  std::lock_guard<std::mutex> lock(g_mu[device_id]);
+  HIPCHK(hipSetDevice(device_id));
+  int rc = ensure_ws(device_id, blocktri_ws_bytes(n, (long)batch, algo));
+  if (rc) return rc;
+  DeviceWs &w = g_ws[device_id];
+  const size_t nblk = (size_t)batch * n * bs * bs, nbor = (size_t)batch * n * bs * (nb ? nb : 1), nrow = (size_t)n * bs + nb;
+  const size_t ny = (size_t)batch * n * bs * (1 + nb);
+  DevBuf<double> bd, bl, bu, bb, br, by;
+  HIPCHK(bd.alloc(nblk)); HIPCHK(bl.alloc(nblk)); HIPCHK(bu.alloc(nblk)); HIPCHK(bb.alloc(nbor)); HIPCHK(br.alloc(batch * nrow)); HIPCHK(by.alloc(ny));
+  HIPCHK(hipMemcpy(bd.d, diag, nblk * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(bl.d, lower, nblk * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(bu.d, upper, nblk * sizeof(double), hipMemcpyHostToDevice));
+  if (nb) HIPCHK(hipMemcpy(bb.d, border, (size_t)batch * n * bs * nb * sizeof(double), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(br.d, rhs, batch * nrow * sizeof(double), hipMemcpyHostToDevice));
+  int singular = 0;
+  rc = blocktri_run((long)batch, n, bs, nb, bd.d, bl.d, bu.d, bb.d, br.d, w.ws, by.d, algo, &singular, 0, w.ev0, w.ev1, g_err, sizeof g_err);
+  if (rc) return rc;
+  w.launched = true;
+  if (singular) { snprintf(g_err, sizeof g_err, "ascent_kkt_solve: singular pivot inside a block (no pivoting)"); return ASCENT_E_ARG; }
+  std::vector<double> Y(ny);
+  HIPCHK(hipMemcpy(Y.data(), by.d, ny * sizeof(double), hipMemcpyDeviceToHost));
+  // close the border on the host: S = d - B'Y_B,  y = S^-1 (s - B'Y_r),  x = Y_r - Y_B y
+  const int nc = 1 + nb;
+  std::vector<double> S((size_t)nb * nb), t(nb), yv(nb);
+  for (int64_t q = 0; q < batch; q++) {
+    const double *Yq = Y.data() + (size_t)q * n * bs * nc;
+    const double *Bq = nb ? border + (size_t)q * n * bs * nb : nullptr;
+    const double *rq = rhs + (size_t)q * nrow;
+    double *xq = sol + (size_t)q * nrow;
+    for (int a = 0; a < nb; a++) {
+      t[a] = rq[(size_t)n * bs + a];
+      for (int b = 0; b < nb; b++) S[(size_t)a * nb + b] = border_diag[((size_t)q * nb + a) * nb + b];
+      for (size_t r = 0; r < (size_t)n * bs; r++) {
+        const double ba = Bq[r * nb + a];
+        t[a] -= ba * Yq[r * nc];
+        for (int b = 0; b < nb; b++) S[(size_t)a * nb + b] -= ba * Yq[r * nc + 1 + b];
+      }
+    }
+    for (int a = 0; a < nb; a++) {            // Gaussian elimination with partial pivoting on [S | t]
+      int pv = a;
+      for (int r = a + 1; r < nb; r++) if (std::fabs(S[(size_t)r * nb + a]) > std::fabs(S[(size_t)pv * nb + a])) pv = r;
+      if (S[(size_t)pv * nb + a] == 0.0) { snprintf(g_err, sizeof g_err, "ascent_kkt_solve: singular border Schur complement"); return ASCENT_E_ARG; }
+      if (pv != a) { for (int b = 0; b < nb; b++) std::swap(S[(size_t)a * nb + b], S[(size_t)pv * nb + b]); std::swap(t[a], t[pv]); }
+      for (int r = a + 1; r < nb; r++) {
+        const double f = S[(size_t)r * nb + a] / S[(size_t)a * nb + a];
+        for (int b = a; b < nb; b++) S[(size_t)r * nb + b] -= f * S[(size_t)a * nb + b];
+        t[r] -= f * t[a];
+      }
+    }
+    for (int a = nb - 1; a >= 0; a--) {
+      double v = t[a];
+      for (int b = a + 1; b < nb; b++) v -= S[(size_t)a * nb + b] * yv[b];
+      yv[a] = v / S[(size_t)a * nb + a];
+    }
+    for (size_t r = 0; r < (size_t)n * bs; r++) {
+      double v = Yq[r * nc];
+      for (int b = 0; b < nb; b++) v -= Yq[r * nc + 1 + b] * yv[b];
+      xq[r] = v;
+    }
+    for (int a = 0; a < nb; a++) xq[(size_t)n * bs + a] = yv[a];
+  }
+  return ASCENT_OK;
 }
 
 }  // extern "C"

@@ -210,6 +210,30 @@ def coast_batch(params, final_state: np.ndarray, coast_nodes: int = 200, device:
     return dict(traj=traj, tf=tf, periapsis_alt=aps[0], apoapsis_alt=aps[1])
 
 
+def kkt_solve(diag, lower, upper, rhs, border=None, border_diag=None, algo="pcr", device: int = 0):
+    """Generic bordered block-tridiagonal solve on the GPU (ascent_kkt_solve, include/ascent.h).
+    diag / lower / upper: (batch, n, bs, bs); rhs: (batch, n*bs + nb); border: (batch, n, bs, nb); border_diag: (batch, nb, nb).
+    algo: "thomas" (block elimination serial in the node index) or "pcr" (parallel cyclic reduction over the nodes).
+    Returns (solution (batch, n*bs + nb), device milliseconds of the solve)."""
+    L = _lib.load()
+    D = np.ascontiguousarray(diag, dtype=np.float64)
+    B, n, bs, _ = D.shape
+    Lo = np.ascontiguousarray(lower, dtype=np.float64); Up = np.ascontiguousarray(upper, dtype=np.float64)
+    nb = 0 if border is None else int(np.shape(border)[-1])
+    r = np.ascontiguousarray(rhs, dtype=np.float64)
+    if Lo.shape != D.shape or Up.shape != D.shape or r.shape != (B, n * bs + nb):
+        raise ValueError("inconsistent shapes")
+    bo = bd = None
+    if nb:
+        bo = np.ascontiguousarray(border, dtype=np.float64); bd = np.ascontiguousarray(border_diag, dtype=np.float64)
+        if bo.shape != (B, n, bs, nb) or bd.shape != (B, nb, nb):
+            raise ValueError("inconsistent border shapes")
+    sol = np.empty_like(r)
+    _lib.check(L.ascent_kkt_solve(B, n, bs, nb, _ptr(D), _ptr(Lo), _ptr(Up), _ptr(bo), _ptr(bd), _ptr(r), _ptr(sol), device,
+                                  {"thomas": 0, "pcr": 1}[algo]))
+    return sol, L.ascent_last_kernel_ms(device)
+
+
 def solve_batch_torch(params_t, nt: int = 200, tol: float = 1e-9, max_iter: int = 300, guess_t=None,
                       warm_start: int = 0, mu_init: float = 0.0, want_traj: bool = True, want_blob: bool = False,
                       out: dict | None = None, sync: bool = False, coarse_nodes: int = 0, scheme=0,
