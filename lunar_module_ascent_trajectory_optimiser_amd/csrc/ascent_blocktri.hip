@@ -130,7 +130,7 @@ __global__ __launch_bounds__(WAVE) void bt_invert(int n, double *ws, int *flag) 
   int bad = 0;
   const Blk Di = binv(lm, lv, bload(w + B_D * GRID_D), bad);
   bstore(w + B_I * GRID_D, Di);
-  if (bad && threadIdx.x == 0) atomicOr(flag, 1);
+  if (bad && threadIdx.x == 0) atomicOr(flag + blockIdx.y, 1);
 }
 
 // one PCR level: node i eliminates its couplings to i-s and i+s
@@ -166,7 +166,7 @@ __global__ __launch_bounds__(WAVE) void bt_pcr_level(int n, int s, const double 
   const Blk Di = binv(lm, lv, D, bad);
   bstore(o + B_L * GRID_D, Ln); bstore(o + B_D * GRID_D, D); bstore(o + B_U * GRID_D, Un); bstore(o + B_R * GRID_D, R);
   bstore(o + B_I * GRID_D, Di);
-  if (bad && threadIdx.x == 0) atomicOr(flag, 1);
+  if (bad && threadIdx.x == 0) atomicOr(flag + sys, 1);
 }
 
 // X_i = Dinv_i R_i, written in the caller's layout: Y[batch][n][bs][1+nb] (column 0: T^-1 rhs, the rest: T^-1 border)
@@ -218,7 +218,13 @@ __global__ __launch_bounds__(WAVE) void bt_thomas(int n, int bs, int nb, double 
       if (r < bs && c < 1 + nb) Y[(((size_t)sys * n + i) * bs + r) * (1 + nb) + c] = Xn.v[q];
     }
   }
-  if (bad && threadIdx.x == 0) atomicOr(flag, 1);
+  if (bad && threadIdx.x == 0) atomicOr(flag + sys, 1);
+}
+
+__global__ void bt_any(const int *flags, long batch, int *out) {
+  int any = 0;
+  for (long q = threadIdx.x; q < batch; q += blockDim.x) any |= flags[q];
+  if (any) atomicOr(out, 1);
 }
 
 }  // namespace
@@ -226,8 +232,9 @@ __global__ __launch_bounds__(WAVE) void bt_thomas(int n, int bs, int nb, double 
 namespace ascent {
 
 size_t blocktri_ws_bytes(int n, long batch, int algo) {
-  return (size_t)batch * n * node_doubles() * sizeof(double) * (algo == 1 ? 2 : 1) + 64;
+  return (size_t)batch * n * node_doubles() * sizeof(double) * (algo == 1 ? 2 : 1) + ((size_t)batch + 16) * sizeof(int);
 }
+size_t blocktri_node_doubles() { return node_doubles(); }
 
 #define BCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf(err, errlen, "%s: %s", #call, hipGetErrorString(e_)); return ASCENT_E_HIP; } } while (0)
 
@@ -236,8 +243,8 @@ int blocktri_run(long batch, int n, int bs, int nb, const double *ddiag, const d
                  const double *dborder, const double *drhs, double *ws, double *dY, int algo, int *singular,
                  hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, char *err, size_t errlen) {
   const size_t per = (size_t)batch * n * node_doubles();
-  int *flag = (int *)((char *)ws + per * sizeof(double) * (algo == 1 ? 2 : 1));
-  BCHK(hipMemsetAsync(flag, 0, sizeof(int), stream));
+  int *flag = (int *)((char *)ws + per * sizeof(double) * (algo == 1 ? 2 : 1));     // [batch] per-system flags + 1 summary
+  BCHK(hipMemsetAsync(flag, 0, ((size_t)batch + 1) * sizeof(int), stream));
   const dim3 g((unsigned)n, (unsigned)batch);
   hipLaunchKernelGGL(bt_pack, g, dim3(WAVE), 0, stream, batch, n, bs, nb, ddiag, dlower, dupper, dborder, drhs, ws);
   BCHK(hipGetLastError());
@@ -255,8 +262,25 @@ int blocktri_run(long batch, int n, int bs, int nb, const double *ddiag, const d
   }
   BCHK(hipGetLastError());
   if (ev1) BCHK(hipEventRecord(ev1, stream));
-  BCHK(hipMemcpyAsync(singular, flag, sizeof(int), hipMemcpyDeviceToHost, stream));
+  hipLaunchKernelGGL(bt_any, dim3(1), dim3(256), 0, stream, (const int *)flag, batch, flag + batch);
+  BCHK(hipMemcpyAsync(singular, flag + batch, sizeof(int), hipMemcpyDeviceToHost, stream));
   BCHK(hipStreamSynchronize(stream));
+  return ASCENT_OK;
+}
+
+// PCR on blocks the caller has already assembled in the workspace image (node_doubles() per node: L, D, U, R, Dinv as
+// [4][64] accumulator-layout images; `a` = assembled buffer, `b` = scratch of the same size).  Asynchronous.
+// dY [batch][n][bs][1+nb]; dflag [batch]: nonzero where a pivot vanished.
+int blocktri_pcr_assembled(long batch, int n, int bs, int nb, double *a, double *b, double *dY, int *dflag, hipStream_t stream,
+                           char *err, size_t errlen) {
+  const dim3 g((unsigned)n, (unsigned)batch);
+  hipLaunchKernelGGL(bt_invert, g, dim3(WAVE), 0, stream, n, a, dflag);
+  for (int s = 1; s < n; s *= 2) {
+    hipLaunchKernelGGL(bt_pcr_level, g, dim3(WAVE), 0, stream, n, s, (const double *)a, b, dflag);
+    double *t = a; a = b; b = t;
+  }
+  hipLaunchKernelGGL(bt_finish, g, dim3(WAVE), 0, stream, n, bs, nb, (const double *)a, dY);
+  BCHK(hipGetLastError());
   return ASCENT_OK;
 }
 

@@ -16,4 +16,12 @@ int blocktri_run(long batch, int n, int bs, int nb, const double *ddiag, const d
                  const double *dborder, const double *drhs, double *ws, double *dY, int algo, int *singular,
                  hipStream_t stream, hipEvent_t ev0, hipEvent_t ev1, char *err, size_t errlen);
 
+// doubles per node of the workspace image: blocks L, D, U, R, Dinv, each [4][64] in the MFMA accumulator layout
+// (lane l, register q: row (l>>4) + 4q, column l&15)
+size_t blocktri_node_doubles();
+
+// PCR on blocks already assembled in that image (buffer a; b = scratch of the same size); asynchronous on `stream`.
+int blocktri_pcr_assembled(long batch, int n, int bs, int nb, double *a, double *b, double *dY, int *dflag, hipStream_t stream,
+                           char *err, size_t errlen);
+
 }  // namespace ascent

@@ -31,6 +31,7 @@
 #include "ascent_device.hpp"
 #include "ascent_tile.hpp"
 #include "ascent_dense.hpp"
+#include "ascent_blocktri.hpp"
 
 using namespace ascent;
 
@@ -51,10 +52,10 @@ enum {  // scalar record
   X_S,                       // 10 scalars of the iterate: th zlt zut s1 s2 zs1 zs2 nu3 nu1 nu2
   X_D = X_S + 10,            // 10 scalars of the step
   X_T = X_D + 10,            // 10 trial scalars
-  X_REFAC = X_T + 10,
+  X_REFAC = X_T + 10, X_RTH, X_DW,
   NSCAL = 64
 };
-enum { ST_TRIAL = 0, ST_DONE = 3 };
+enum { ST_TRIAL = 0, ST_NEWTON = 1, ST_DONE = 3 };     // ST_NEWTON: waiting for the PCR solve of its Newton system
 
 struct DGeo {
   int K, scheme, terminal;
@@ -499,6 +500,9 @@ ASC_DEV double ginv(Lds8 &L, double m, int &bad) {
 // ==============================================================================================================
 struct Border { double Oth, Otn, Onn, oth, onu; };     // Omega (2x2 symmetric) and omega of the value function
 
+// MODE 0: decisions + Riccati solve + step (the whole Newton iteration).  MODE 1: decisions only; an NLP that needs a Newton
+// step is handed to the PCR kernels (pc_assemble -> ascent_blocktri's cyclic reduction -> pc_step) in state ST_NEWTON.
+template <int MODE>
 __global__ __launch_bounds__(WAVE) void d_newton(const ascent_params *params, long batch, DGeo g, double *ws, int max_iter,
                                                  double tol, int probe, const double *probe_dw, int *counters) {
   __shared__ Lds8 L;
@@ -595,6 +599,13 @@ __global__ __launch_bounds__(WAVE) void d_newton(const ascent_params *params, lo
     }
   } else {
     dw = probe_dw[p];
+  }
+  if (MODE == 1) {
+    if (l == 0) {
+      sc[X_MU] = mu; sc[X_NUP] = nu_pen; sc[X_RTH] = rth; sc[X_DW] = dw; sc[X_STATE] = ST_NEWTON;
+      atomicAdd(&counters[0], 1);
+    }
+    return;
   }
   // ---- Newton step: backward recursion (repeated with a larger delta_w while the inertia is wrong) ---------------------
   const double hT = (1.0 / K) * d.T, dt = hT * s.th;
@@ -808,6 +819,250 @@ __global__ __launch_bounds__(WAVE) void d_newton(const ascent_params *params, lo
   }
 }
 
+
+// ==============================================================================================================
+// PCR variant of the Newton solve (small batches / long grids): the same Newton system, ordered by collocation node into
+// 15x15 blocks (7 states, the control, the 7 defect multipliers), solved by parallel cyclic reduction over the nodes on
+// v_mfma_f64_16x16x4_f64 tiles (ascent_blocktri.hip) instead of the serial Riccati recursion: log2(K) levels of one
+// wavefront per node.  Inside a node the EQUATIONS are ordered (defect rows, control row, state rows) against the
+// UNKNOWNS (states, control, multipliers): the diagonal block then starts with the step Jacobian Jb ~ I, so the
+// unpivoted Gauss-Jordan inverse of ascent_blocktri meets unit-size pivots (in the symmetric order the leading block
+// would be the Lagrangian Hessian, which is tiny and indefinite).  PCR exposes no inertia; this variant regularises on
+// the curvature dx'(W + Sigma + delta)dx the merit function needs anyway (the rule of oracle/-side numpy restatement).
+// ==============================================================================================================
+constexpr int PC_NB = 2, PC_BS = 15;
+__global__ __launch_bounds__(WAVE) void pc_assemble(const ascent_params *params, long batch, DGeo g, const double *ws, double *bt,
+                                                    double *bcols, size_t node_doubles) {
+  const long p = blockIdx.y;
+  const int k = blockIdx.x, K = g.K, l = threadIdx.x;
+  const double *w = ws + (size_t)p * g.nlp_doubles();
+  const double *sc = w + g.off_sc();
+  if ((int)sc[X_STATE] != ST_NEWTON) return;
+  const Der d = derive_t(params[p], g.terminal);
+  const Scal s = load_scal(sc, X_S);
+  const double mu = sc[X_MU], dw = sc[X_DW];
+  const double *it = w + g.off_it((int)sc[X_CUR]), *nv = w + g.off_nv();
+  const double *rk = w + g.off_rec() + (size_t)k * NGRID * 64;
+  const double *rn = rk + NGRID * 64;                         // record of step k+1 (valid if k+1 < K)
+  const bool nxt = k + 1 < K, last = k == K - 1;
+  const double hT = (1.0 / K) * d.T, dt = hT * s.th;
+  const double a_ = it[(O_Z + IA) * K + k], m_ = it[(O_Z + IM) * K + k], u_ = it[O_U * K + k];
+  const double id0 = rcp(a_), id1 = rcp(d.aub - a_), id2 = rcp(m_), id3 = rcp(1.0 - m_), id4 = rcp(u_ + 1.0), id5 = rcp(1.0 - u_);
+  const double siga = it[(O_ZB + 0) * K + k] * id0 + it[(O_ZB + 1) * K + k] * id1;
+  const double sigm = it[(O_ZB + 2) * K + k] * id2 + it[(O_ZB + 3) * K + k] * id3;
+  const double sigu = it[(O_ZB + 4) * K + k] * id4 + it[(O_ZB + 5) * K + k] * id5;
+  double QT[28], rt4[4] = {0.0, 0.0, 0.0, 0.0}, e3g[4] = {0.0, 0.0, 0.0, 0.0};
+  ASC_UNROLL
+  for (int q = 0; q < 28; q++) QT[q] = 0.0;
+  if (last) {
+    double zK[7];
+    for (int q = 0; q < 7; q++) zK[q] = it[(O_Z + q) * K + K - 1];
+    const Terminal tm = terminal_eval(d, zK);
+    const double is1 = rcp(s.s1), is2 = rcp(s.s2);
+    const double sig1 = s.zs1 * is1 + dw, sig2 = s.zs2 * is2 + dw, rs1 = -mu * is1 - s.nu1, rs2 = -mu * is2 - s.nu2;
+    const double w1 = s.nu1 + sig1 * (tm.g1 - s.s1) + rs1, w2 = s.nu2 + sig2 * (tm.g2 - s.s2) + rs2;
+    terminal_hessian(QT, tm, s.nu3, s.nu1, s.nu2, sig1, sig2);
+    rt4[0] = s.nu3 * tm.e3g[0] + w1 * tm.g1g[0]; rt4[1] = s.nu3 * tm.e3g[1] + w1 * tm.g1g[1];
+    rt4[2] = s.nu3 * tm.e3g[2] + w2 * tm.g2g[0]; rt4[3] = s.nu3 * tm.e3g[3] + w2 * tm.g2g[1];
+    ASC_UNROLL
+    for (int q = 0; q < 4; q++) e3g[q] = tm.e3g[q];
+  }
+  double *o = bt + ((size_t)p * K + k) * node_doubles;
+  const int c = l & 15;
+  ASC_UNROLL
+  for (int q = 0; q < 4; q++) {
+    const int rp = (l >> 4) + 4 * q;                          // physical row: 0-6 defect rows, 7 control row, 8-14 state rows
+    double L = 0.0, D = 0.0, U = 0.0, R = 0.0;
+    if (rp < 7) {                                             // defect row i: Ja dz_{k-1} + Jb dz_k + Ju du + Jth dth = -c
+      const int i = rp;
+      if (c < 7) { D = rk[G_JB * 64 + i * 8 + c]; if (k > 0) L = rk[G_JA * 64 + i * 8 + c]; }
+      else if (c == 7) D = rk[G_V * 64 + 1 * 8 + i];
+      if (c == 0) R = -rk[G_V * 64 + 0 * 8 + i];
+      else if (c == 1) R = rk[G_V * 64 + 2 * 8 + i];
+    } else if (rp == 7) {                                     // control row
+      if (c == 7) D = sigu + dw;
+      else if (c >= 8 && c < 15) D = rk[G_V * 64 + 1 * 8 + (c - 8)];
+      if (c == 0) R = -(-dt * d.alpha * it[(O_L + IW) * K + k] + mu * (id5 - id4));
+      else if (c == 1) R = nv[(NV_P + 8) * K + k];
+    } else if (rp < 15) {                                     // state row i: stationarity with respect to z_k
+      const int i = rp - 8;
+      if (c < 7) {
+        D = rk[G_HBB * 64 + i * 8 + c] + (nxt ? rn[G_HAA * 64 + i * 8 + c] : 0.0);
+        if (i == c) D += (i == IA ? siga : i == IM ? sigm : 0.0) + dw;
+        if (last) {       // (compile-time indices: a runtime index into QT would put it into scratch memory)
+          ASC_UNROLL
+          for (int a = 0; a < 4; a++) {
+            ASC_UNROLL
+            for (int b = 0; b < 4; b++) D += (i == a && c == b) ? QT[sid(a, b)] : 0.0;
+          }
+        }
+        if (k > 0) L = rk[G_HAB * 64 + c * 8 + i];            // (Hab_k)'
+        if (nxt) U = rn[G_HAB * 64 + i * 8 + c];
+      } else if (c >= 8 && c < 15) {
+        D = rk[G_JB * 64 + (c - 8) * 8 + i];                  // Jb'
+        if (nxt) U = rn[G_JA * 64 + (c - 8) * 8 + i];         // Ja_{k+1}'
+      }
+      if (c == 0) {
+        double rx = nv[(NV_GB + i) * K + k] + (nxt ? nv[(NV_GA + i) * K + k + 1] : 0.0);
+        if (i == IA) rx += mu * (id1 - id0);
+        if (i == IM) rx += mu * (id3 - id2);
+        ASC_UNROLL
+        for (int a = 0; a < 4; a++) rx += (last && i == a) ? rt4[a] : 0.0;
+        R = -rx;
+      } else if (c == 1) {
+        R = rk[G_V * 64 + 4 * 8 + i] + (nxt ? rn[G_V * 64 + 3 * 8 + i] : 0.0);
+      } else if (c == 2) {
+        ASC_UNROLL
+        for (int a = 0; a < 4; a++) R += (last && i == a) ? e3g[a] : 0.0;
+      }
+    } else {
+      D = c == 15 ? 1.0 : 0.0;
+    }
+    o[0 * 256 + q * WAVE + l] = L; o[1 * 256 + q * WAVE + l] = D; o[2 * 256 + q * WAVE + l] = U; o[3 * 256 + q * WAVE + l] = R;
+  }
+  // the two border rows of the (symmetric) matrix over this node's unknowns (z, u, lambda), for the Schur complement
+  if (l < 32) {
+    const int b = l >> 4, cc = l & 15;
+    double v = 0.0;
+    if (b == 0) {
+      if (cc < 7) v = rk[G_V * 64 + 4 * 8 + cc] + (nxt ? rn[G_V * 64 + 3 * 8 + cc] : 0.0);
+      else if (cc == 7) v = nv[(NV_P + 8) * K + k];
+      else if (cc < 15) v = rk[G_V * 64 + 2 * 8 + (cc - 8)];
+    } else {
+      ASC_UNROLL
+      for (int a = 0; a < 4; a++) v += (last && cc == a) ? e3g[a] : 0.0;
+    }
+    bcols[((size_t)p * K + k) * 32 + l] = v;
+  }
+}
+
+// border Schur complement, the step of every node from the PCR solution, bound-multiplier steps, fraction to the boundary,
+// merit bookkeeping; regularisation on the curvature along the step.  One wavefront per NLP, lanes stride over the nodes.
+__global__ __launch_bounds__(WAVE) void pc_step(const ascent_params *params, long batch, DGeo g, double *ws, const double *Y,
+                                                const double *bcols, const int *flags, int probe, int *counters) {
+  const long p = blockIdx.x;
+  const int l = threadIdx.x, K = g.K;
+  double *w = ws + (size_t)p * g.nlp_doubles();
+  double *sc = w + g.off_sc();
+  if ((int)sc[X_STATE] != ST_NEWTON) return;
+  const Der d = derive_t(params[p], g.terminal);
+  const Scal s = load_scal(sc, X_S);
+  const double mu = sc[X_MU], dw = sc[X_DW], rth = sc[X_RTH], c1 = sc[X_C1], sl = sc[X_SL];
+  double nu_pen = sc[X_NUP];
+  const double *it = w + g.off_it((int)sc[X_CUR]), *nv = w + g.off_nv();
+  double *st = w + g.off_st();
+  const double *Yp = Y + (size_t)p * K * PC_BS * 3, *Bp = bcols + (size_t)p * K * 32;
+  double zK[7];
+  for (int q = 0; q < 7; q++) zK[q] = it[(O_Z + q) * K + K - 1];
+  const Terminal tm = terminal_eval(d, zK);
+  // ---- Schur complement of the two border unknowns (theta, nu3) ---------------------------------------------------------
+  double hth = 0.0, s11 = 0.0, s12 = 0.0, s21 = 0.0, s22 = 0.0, t1 = 0.0, t2 = 0.0;
+  for (int k = l; k < K; k += WAVE) {
+    hth += nv[(NV_P + 9) * K + k];
+    const double *y = Yp + (size_t)k * PC_BS * 3, *b = Bp + (size_t)k * 32;
+    for (int r = 0; r < PC_BS; r++) {
+      const double bt_ = b[r], bn = b[16 + r], yr = y[r * 3], yt = y[r * 3 + 1], yn = y[r * 3 + 2];
+      s11 -= bt_ * yt; s12 -= bt_ * yn; t1 -= bt_ * yr;
+      s21 -= bn * yt; s22 -= bn * yn; t2 -= bn * yr;
+    }
+  }
+  hth = wsum(hth); s11 = wsum(s11); s12 = wsum(s12); s21 = wsum(s21); s22 = wsum(s22); t1 = wsum(t1); t2 = wsum(t2);
+  const double itl = rcp(s.th - d.tlb), itu = rcp(d.tub - s.th);
+  s11 += s.zlt * itl + s.zut * itu + dw + hth;
+  t1 += -(rth + mu * (itu - itl));
+  t2 += -tm.e3;
+  const double det = s11 * s22 - s12 * s21;
+  const double dth = (t1 * s22 - s12 * t2) / det, dnu3 = (s11 * t2 - s21 * t1) / det;
+  int ok = isfinite(dth) && isfinite(dnu3) && !flags[p];
+  // ---- the step of every node; bound multipliers; fraction to the boundary ------------------------------------------------
+  const double tau = fmax(0.99, 1.0 - mu);
+  double rmax = 0.0, gsum = 0.0, adu = 1.0, cl = 0.0, dx2 = 0.0;
+  for (int k = l; k < K; k += WAVE) {
+    const double *y = Yp + (size_t)k * PC_BS * 3;
+    double x[PC_BS];
+    ASC_UNROLL
+    for (int r = 0; r < PC_BS; r++) x[r] = y[r * 3] - y[r * 3 + 1] * dth - y[r * 3 + 2] * dnu3;
+    ASC_UNROLL
+    for (int q = 0; q < 7; q++) { st[(O_Z + q) * K + k] = x[q]; st[(O_L + q) * K + k] = x[8 + q]; dx2 += x[q] * x[q]; }
+    st[O_U * K + k] = x[7];
+    dx2 += x[7] * x[7];
+    const double dza = x[IA], dzm = x[IM], du = x[7];
+    const double a_ = it[(O_Z + IA) * K + k], m_ = it[(O_Z + IM) * K + k], u_ = it[O_U * K + k];
+    const double id[6] = {rcp(a_), rcp(d.aub - a_), rcp(m_), rcp(1.0 - m_), rcp(u_ + 1.0), rcp(1.0 - u_)};
+    ASC_FTBR(rmax, id[0], dza); ASC_FTBR(rmax, id[1], -dza);
+    ASC_FTBR(rmax, id[2], dzm); ASC_FTBR(rmax, id[3], -dzm);
+    ASC_FTBR(rmax, id[4], du); ASC_FTBR(rmax, id[5], -du);
+    gsum += dza * (id[1] - id[0]) + dzm * (id[3] - id[2]) + du * (id[5] - id[4]);
+    const double dx3[3] = {dza, dzm, du};
+    ASC_UNROLL
+    for (int b = 0; b < 3; b++) {
+      const double zl = it[(O_ZB + 2 * b) * K + k], zu = it[(O_ZB + 2 * b + 1) * K + k];
+      const double dzl = id[2 * b] * (mu - zl * dx3[b]) - zl, dzu = id[2 * b + 1] * (mu + zu * dx3[b]) - zu;
+      ASC_FTB(adu, zl, dzl);
+      ASC_FTB(adu, zu, dzu);
+      st[(O_ZB + 2 * b) * K + k] = dzl; st[(O_ZB + 2 * b + 1) * K + k] = dzu;
+    }
+    const double *rk = w + g.off_rec() + (size_t)k * NGRID * 64;
+    ASC_UNROLL
+    for (int q = 0; q < 7; q++) cl += rk[G_V * 64 + q] * (it[(O_L + q) * K + k] + x[8 + q]);
+  }
+  rmax = wmax(rmax); gsum = wsum(gsum); adu = wmin(adu); cl = wsum(cl); dx2 = wsum(dx2);
+  // ---- scalars of the step, merit bookkeeping (as d_newton) ---------------------------------------------------------------
+  const double is1 = rcp(s.s1), is2 = rcp(s.s2);
+  const double sig1 = s.zs1 * is1 + dw, sig2 = s.zs2 * is2 + dw, rs1 = -mu * is1 - s.nu1, rs2 = -mu * is2 - s.nu2;
+  double dzKx = 0.0, dzKy = 0.0, dzKvx = 0.0, dzKvy = 0.0;
+  {
+    const double *y = Yp + (size_t)(K - 1) * PC_BS * 3;
+    dzKx = y[IX * 3] - y[IX * 3 + 1] * dth - y[IX * 3 + 2] * dnu3; dzKy = y[IY * 3] - y[IY * 3 + 1] * dth - y[IY * 3 + 2] * dnu3;
+    dzKvx = y[IVX * 3] - y[IVX * 3 + 1] * dth - y[IVX * 3 + 2] * dnu3; dzKvy = y[IVY * 3] - y[IVY * 3 + 1] * dth - y[IVY * 3 + 2] * dnu3;
+  }
+  Scal ds;
+  ds.th = dth; ds.nu3 = dnu3;
+  ds.s1 = (tm.g1 - s.s1) + tm.g1g[0] * dzKx + tm.g1g[1] * dzKy;
+  ds.s2 = (tm.g2 - s.s2) + tm.g2g[0] * dzKvx + tm.g2g[1] * dzKvy;
+  ds.nu1 = sig1 * ds.s1 + rs1;
+  ds.nu2 = sig2 * ds.s2 + rs2;
+  ds.zs1 = mu / s.s1 - s.zs1 - s.zs1 / s.s1 * ds.s1;
+  ds.zs2 = mu / s.s2 - s.zs2 - s.zs2 / s.s2 * ds.s2;
+  const double dl_ = s.th - d.tlb, dU = d.tub - s.th;
+  ds.zlt = mu / dl_ - s.zlt - s.zlt / dl_ * ds.th;
+  ds.zut = mu / dU - s.zut + s.zut / dU * ds.th;
+  double apr = 1.0;
+  if (rmax * apr > tau) apr = tau / rmax;
+  ASC_FTB(apr, dl_, ds.th); ASC_FTB(apr, dU, -ds.th);
+  ASC_FTB(apr, s.s1, ds.s1); ASC_FTB(apr, s.s2, ds.s2);
+  ASC_FTB(adu, s.zlt, ds.zlt); ASC_FTB(adu, s.zut, ds.zut);
+  ASC_FTB(adu, s.zs1, ds.zs1); ASC_FTB(adu, s.zs2, ds.zs2);
+  double gd = mu * gsum;
+  gd += ds.th * (1.0 - mu / dl_ + mu / dU) - mu * ds.s1 / s.s1 - mu * ds.s2 / s.s2;
+  cl += tm.e3 * (s.nu3 + ds.nu3) + (tm.g1 - s.s1) * (s.nu1 + ds.nu1) + (tm.g2 - s.s2) * (s.nu2 + ds.nu2);
+  const double curv = -gd + cl;                 // dx'(W + Sigma + delta_w)dx by the Newton identity
+  dx2 += dth * dth + ds.s1 * ds.s1 + ds.s2 * ds.s2;
+  ok = ok && isfinite(curv) && curv >= 1e-11 * dx2;
+  if (!ok) {                                    // regularise and solve again (this NLP only; state stays ST_NEWTON)
+    if (l == 0) {
+      if (probe) { sc[X_STATE] = ST_DONE; sc[X_STATUS] = ASCENT_REGULARISATION_FAILED; return; }
+      const double ndw = next_delta_w(dw, sc[X_DWL]);
+      if (ndw > 1e10) { sc[X_STATUS] = ASCENT_REGULARISATION_FAILED; sc[X_STATE] = ST_DONE; }
+      else { sc[X_DW] = ndw; sc[X_REFAC] += 1.0; atomicAdd(&counters[0], 1); }
+    }
+    return;
+  }
+  if (c1 > 0.0) {
+    const double need = (gd + 0.5 * fmax(curv, 0.0)) / (0.9 * c1);
+    if (nu_pen < need) nu_pen = need + 1.0;
+  }
+  if (l == 0) {
+    store_scal(sc, X_D, ds);
+    sc[X_NUP] = nu_pen; sc[X_DWL] = dw;
+    sc[X_DM] = gd - nu_pen * c1;
+    sc[X_PHI0] = s.th - mu * sl + nu_pen * c1;
+    sc[X_ALPHA] = apr; sc[X_ADU] = adu;
+    if (probe) { sc[X_STATE] = ST_DONE; sc[X_STATUS] = 0; }
+    else { sc[X_STATE] = ST_TRIAL; atomicAdd(&counters[0], 1); }
+  }
+}
+
 // ==============================================================================================================
 // d_finish: results in the external layouts.  Lane = (NLP, step).
 // ==============================================================================================================
@@ -935,11 +1190,42 @@ size_t dense_ws_bytes(int K, long batch) {
   return (size_t)batch * g.nlp_doubles() * sizeof(double) + 64;
 }
 
+// PCR variant: the dense workspace, then two block images, the PCR solution, the border rows, per-NLP flags
+struct PcrWs { double *bt_a, *bt_b, *Y, *bcols; int *flags; };
+static size_t pcr_extra_doubles(int K, long batch) {
+  return (size_t)batch * K * (2 * blocktri_node_doubles() + PC_BS * 3 + 32) + (size_t)batch + 16;
+}
+size_t dense_pcr_ws_bytes(int K, long batch) { return dense_ws_bytes(K, batch) + pcr_extra_doubles(K, batch) * sizeof(double); }
+static PcrWs pcr_ws(double *ws, int K, long batch) {
+  PcrWs q;
+  double *base = (double *)((char *)ws + dense_ws_bytes(K, batch));
+  const size_t nb = (size_t)batch * K * blocktri_node_doubles();
+  q.bt_a = base; q.bt_b = base + nb; q.Y = base + 2 * nb; q.bcols = q.Y + (size_t)batch * K * PC_BS * 3;
+  q.flags = (int *)(q.bcols + (size_t)batch * K * 32);
+  return q;
+}
+
 #define DCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf(err, errlen, "%s: %s", #call, hipGetErrorString(e_)); return ASCENT_E_HIP; } } while (0)
+
+static int pcr_newton(const ascent_params *dp, long batch, DGeo g, double *ws, int probe, int *counters, hipStream_t stream,
+                      char *err, size_t errlen) {
+  const int K = g.K;
+  const PcrWs q = pcr_ws(ws, K, batch);
+  DCHK(hipMemsetAsync(q.flags, 0, (size_t)batch * sizeof(int), stream));
+  hipLaunchKernelGGL(pc_assemble, dim3((unsigned)K, (unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g, (const double *)ws, q.bt_a,
+                     q.bcols, blocktri_node_doubles());
+  DCHK(hipGetLastError());
+  int rc = blocktri_pcr_assembled(batch, K, PC_BS, PC_NB, q.bt_a, q.bt_b, q.Y, q.flags, stream, err, errlen);
+  if (rc) return rc;
+  hipLaunchKernelGGL(pc_step, dim3((unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g, ws, (const double *)q.Y,
+                     (const double *)q.bcols, (const int *)q.flags, probe, counters);
+  DCHK(hipGetLastError());
+  return ASCENT_OK;
+}
 
 int dense_run(const ascent_params *dp, long batch, int K, int scheme, int terminal, double *ws, const double *dguess, int warm,
               int max_iter, double tol, double mu0, double *dtraj, double *dtf, int *dstatus, int *diters, double *dblob,
-              hipStream_t stream, char *err, size_t errlen) {
+              hipStream_t stream, char *err, size_t errlen, int pcr) {
   DGeo g{K, scheme, terminal};
   int *counters = (int *)((char *)ws + (size_t)batch * g.nlp_doubles() * sizeof(double));
   static int *host_cnt_dev[64] = {nullptr};
@@ -957,8 +1243,16 @@ int dense_run(const ascent_params *dp, long batch, int K, int scheme, int termin
     for (int r = 0; r < burst; r++, round++) {
       DCHK(hipMemsetAsync(counters, 0, sizeof(int), stream));
       hipLaunchKernelGGL(d_eval, ngrid, dim3(WAVE), 0, stream, dp, batch, g, ws);
-      hipLaunchKernelGGL(d_newton, dim3((unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g, ws, max_iter, tol, 0,
-                         (const double *)nullptr, counters);
+      if (!pcr) {
+        hipLaunchKernelGGL(d_newton<0>, dim3((unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g, ws, max_iter, tol, 0,
+                           (const double *)nullptr, counters);
+      } else {
+        hipLaunchKernelGGL(d_newton<1>, dim3((unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g, ws, max_iter, tol, 0,
+                           (const double *)nullptr, counters);
+        // (an NLP that goes on is counted by both kernels; the host only asks whether the counter is zero)
+        const int rc = pcr_newton(dp, batch, g, ws, 0, counters, stream, err, errlen);
+        if (rc) return rc;
+      }
       DCHK(hipGetLastError());
     }
     DCHK(hipMemcpyAsync(host_cnt, counters, sizeof(int), hipMemcpyDeviceToHost, stream));
@@ -972,7 +1266,7 @@ int dense_run(const ascent_params *dp, long batch, int K, int scheme, int termin
 
 int dense_probe(const ascent_params *dp, long batch, int K, int scheme, int terminal, double *ws, const double *diterate,
                 const double *dmu, const double *ddw, bool step_too, double *dstep, int *dinertia, double *drecords,
-                hipStream_t stream, char *err, size_t errlen) {
+                hipStream_t stream, char *err, size_t errlen, int pcr) {
   DGeo g{K, scheme, terminal};
   int *counters = (int *)((char *)ws + (size_t)batch * g.nlp_doubles() * sizeof(double));
   const dim3 ngrid((unsigned)((K + WAVE - 1) / WAVE), (unsigned)batch);
@@ -983,8 +1277,15 @@ int dense_probe(const ascent_params *dp, long batch, int K, int scheme, int term
     hipLaunchKernelGGL(d_dump_records, dim3((unsigned)K, (unsigned)batch), dim3(WAVE), 0, stream, batch, g, ws, drecords);
     DCHK(hipGetLastError());
   }
-  if (step_too) {
-    hipLaunchKernelGGL(d_newton, dim3((unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g, ws, 1 << 30, -1.0, 1, ddw, counters);
+  if (step_too && pcr) {
+    hipLaunchKernelGGL(d_newton<1>, dim3((unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g, ws, 1 << 30, -1.0, 1, ddw, counters);
+    const int rc = pcr_newton(dp, batch, g, ws, 1, counters, stream, err, errlen);
+    if (rc) return rc;
+    hipLaunchKernelGGL(d_finish, ngrid, dim3(WAVE), 0, stream, dp, batch, g, ws, (double *)nullptr, (double *)nullptr, dinertia,
+                       (int *)nullptr, dstep, 1);
+    DCHK(hipGetLastError());
+  } else if (step_too) {
+    hipLaunchKernelGGL(d_newton<0>, dim3((unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g, ws, 1 << 30, -1.0, 1, ddw, counters);
     hipLaunchKernelGGL(d_finish, ngrid, dim3(WAVE), 0, stream, dp, batch, g, ws, (double *)nullptr, (double *)nullptr, dinertia,
                        (int *)nullptr, dstep, 1);
     DCHK(hipGetLastError());

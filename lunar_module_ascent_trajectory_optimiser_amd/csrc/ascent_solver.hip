@@ -908,10 +908,28 @@ __global__ __launch_bounds__(WAVE) void k_terminal_params(const ascent_params *i
   out[p] = q;
 }
 
-bool use_dense_path(const ascent_opts *o) {
+bool use_dense_path(const ascent_opts *o, int64_t batch) {
   if (o->scheme == 2 || o->solver_path == ASCENT_PATH_DENSE) return true;
   const char *e = getenv("ASCENT_PIPELINE");
-  return e && !strcmp(e, "dense") && o->formulation == 0;
+  if (e) return !strcmp(e, "dense") && o->formulation == 0;
+  // A handful of NLPs cannot fill even the 16-lane sweeps of the hand-tuned path (one wavefront per four NLPs, serial over
+  // the nodes: ~5 ms at N=200, ~56 ms at N=2000 whatever the batch); the dense-block path with its Newton systems solved by
+  // cyclic reduction over the nodes spreads ONE NLP over hundreds of wavefronts: 3.2 vs 4.8 ms (N=200), 13 vs 56 ms (N=2000)
+  // for a single NLP, break-even near 8 NLPs (scripts/small_batch_paths.py).  ASCENT_SMALL_BATCH=off keeps the hand-tuned path.
+  const char *sb = getenv("ASCENT_SMALL_BATCH");
+  if (sb && !strcmp(sb, "off")) return false;
+  return o->formulation == 0 && batch <= 8 && !getenv("ASCENT_FACTOR") && !getenv("ASCENT_DENSE_NEWTON_OFF");
+}
+
+// The dense-block path solves its Newton systems either by the serial Riccati recursion of one wavefront per NLP or by
+// parallel cyclic reduction over the collocation nodes (one wavefront per node; ascent_blocktri.hip).  Measured
+// (profiles/r02_c_*): cyclic reduction wins while batch x nodes leaves SIMDs idle, i.e. for a handful of NLPs; the
+// crossover with the serial recursion lies around 100 NLPs.  ASCENT_DENSE_NEWTON=riccati|pcr overrides.
+bool use_pcr_newton(int64_t batch) {
+  const char *e = getenv("ASCENT_DENSE_NEWTON");
+  if (e && !strcmp(e, "pcr")) return true;
+  if (e && !strcmp(e, "riccati")) return false;
+  return batch <= 64;      // scripts/small_batch_paths.py: 13.1 vs 15.8 ms at 64 NLPs (N=200), 248 vs 284 ms (N=2000)
 }
 
 struct DeviceWs {
@@ -1070,9 +1088,10 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
   const size_t rows = 21 * (size_t)K + NSC;
   const int lpt = lanes_per_tile(batch);
   // the trapezoid scheme and the v1 formulation exist in the split pipeline only
-  const bool dense = use_dense_path(o);
+  const bool dense = use_dense_path(o, batch);
+  const bool pcr = dense && use_pcr_newton(batch);
   const bool split = o->scheme == 1 || o->formulation == 1 || use_split_pipeline(batch);
-  rc = ensure_ws(device_id, dense ? dense_ws_bytes(K, (long)batch) : split ? pipeline_ws_bytes(K, (long)batch) : ws_bytes(K, batch, lpt));
+  rc = ensure_ws(device_id, dense ? (pcr ? dense_pcr_ws_bytes(K, (long)batch) : dense_ws_bytes(K, (long)batch)) : split ? pipeline_ws_bytes(K, (long)batch) : ws_bytes(K, batch, lpt));
   if (rc) return rc;
   DeviceWs &w = g_ws[device_id];
   const double mu0 = o->mu_init > 0 ? o->mu_init : (o->warm_start ? 1e-4 : 0.1);
@@ -1146,7 +1165,7 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
     int *st_l = fin ? dstatus : w.st_c, *it_l = fin ? diters : w.it_c;
     if (dense) {
       rc = dense_run(dp, (long)batch, Kl, (int)o->scheme, 0, w.ws, g_l, warm_l, (int)o->max_iter, tol_l, mu_l, traj_l, tf_l, st_l,
-                     it_l, blob_l, stream, g_err, sizeof g_err);
+                     it_l, blob_l, stream, g_err, sizeof g_err, pcr ? 1 : 0);
       if (rc) return rc;
     } else if (split) {
       rc = pipeline_run(dp, (long)batch, Kl, (int)o->scheme, (int)o->formulation, w.ws, g_l, warm_l, (int)o->max_iter, tol_l, mu_l,
@@ -1184,7 +1203,7 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
 // which kernels a parity-surface call runs: an explicit path, or (AUTO) the one ascent_solve_batch would take
 static int resolve_path(int path, const ascent_opts *o, int64_t batch) {
   if (path == ASCENT_PATH_AUTO) {
-    if (use_dense_path(o)) return ASCENT_PATH_DENSE;
+    if (use_dense_path(o, batch)) return ASCENT_PATH_DENSE;
     const bool split = o->scheme == 1 || o->formulation == 1 || use_split_pipeline(batch);
     if (!split) return ASCENT_PATH_FUSED;
     bool wide = batch <= 4096;
@@ -1254,7 +1273,8 @@ int ascent_kkt_step_path(const ascent_params *p, int64_t batch, const ascent_opt
   const int K = o->n_nodes - 1;
   const size_t rows = 21 * (size_t)K + NSC;
   const int lpt = lanes_per_tile(batch);
-  rc = ensure_ws(device_id, path == ASCENT_PATH_DENSE ? dense_ws_bytes(K, (long)batch)
+  const bool pcr_probe = path == ASCENT_PATH_DENSE && use_pcr_newton(batch);
+  rc = ensure_ws(device_id, path == ASCENT_PATH_DENSE ? (pcr_probe ? dense_pcr_ws_bytes(K, (long)batch) : dense_ws_bytes(K, (long)batch))
                             : path == ASCENT_PATH_FUSED ? ws_bytes(K, batch, lpt) : pipeline_ws_bytes(K, (long)batch));
   if (rc) return rc;
   DevBuf<ascent_params> bp;
@@ -1273,7 +1293,7 @@ int ascent_kkt_step_path(const ascent_params *p, int64_t batch, const ascent_opt
   }
   if (path == ASCENT_PATH_DENSE) {
     rc = dense_probe(bp.d, (long)batch, K, (int)o->scheme, 0, g_ws[device_id].ws, bit.d, bmu.d, bdw.d, true, bst.d, bin.d, nullptr,
-                     0, g_err, sizeof g_err);
+                     0, g_err, sizeof g_err, pcr_probe ? 1 : 0);
     if (rc) return rc;
   } else if (path == ASCENT_PATH_FUSED) {
     hipLaunchKernelGGL(k_kkt_step, dim3((unsigned)((batch + lpt - 1) / lpt)), dim3(WAVE), 0, 0, bp.d, (long)batch, lpt, K,

@@ -21,6 +21,7 @@
 #include <math.h>
 #include <stdlib.h>
 #include <string.h>
+#include <stdio.h>
 
 #define NS 7
 enum { IX, IY, IVX, IVY, IA, IW, IM };
@@ -511,6 +512,9 @@ void oracle_set_barrier_schedule(double mu0, double keps, double kmu, double thm
 /* warm: 0 = built-in cold-start guess, 1 = primal part of the blob, 2 = the full primal-dual blob (multipliers and
  * slacks kept, floored away from zero).  A blob whose theta is not positive is treated as "no guess" (that is how the
  * nested iteration marks problems whose coarse solve failed).  mu0 <= 0: 0.1 cold, 1e-4 warm. */
+static int g_trace = 0;       /* oracle_set_trace(1): one line per interior-point iteration on stderr (diagnostics) */
+void oracle_set_trace(int on) { g_trace = on; }
+
 static int solve_one(const oparams *prm, int nt, int max_iter, double tol, int warm, double mu0, double *blob,
                      int *iters_out, int *nreg_out) {
   int K = nt - 1; oder d; derive(prm, &d);
@@ -599,6 +603,8 @@ static int solve_one(const oparams *prm, int nt, int max_iter, double tol, int w
       alpha *= 0.5;
     }
     if (!ok) { status = ST_LINESEARCH; break; }
+    if (g_trace) fprintf(stderr, "[oracle] K=%d iter %2d mu %.1e E0 %.2e Emu %.2e alpha %.3g (apr %.3g) adu %.3g dw %.1e nu_pen %.2g c1 %.2e\n", K, iter, mu, e0,
+                         kkt_error(&d, w, &it, mu), alpha, apr, adu, dw, nu_pen, c1);
     for (int i = 0; i < 8 * K; i++) blob[i] += alpha * w->step[i];
     for (int i = 0; i < 7 * K; i++) it.lam[i] += alpha * st.lam[i];
     for (int i = 0; i < 6 * K; i++) it.zb[i] += adu * st.zb[i];

@@ -188,9 +188,13 @@ def test_config5_high_resolution_burn_then_coast():
     # mesh refinement: the same problems at N = 200 land within 0.01 s
     r2 = A.solve_batch(S[:8], 200, tol=1e-9, scheme=2, terminal="ellipse")
     assert np.abs(r2.final_time() - r.final_time()[:8]).max() < 0.01
+    # the generalised numpy oracle's solution of the nominal problem at this size (17 minutes of sympy-generated numpy; the
+    # fixture was made at tol 1e-10: with 12 000 bound terms the barrier's pull on t_f is 5e-8 at tol 1e-9)
     by = _fixtures()
     if (2000, 2, "periapsis") in by:
-        assert abs(r.tf[0] - by[(2000, 2, "periapsis")]["tf"]) <= 1e-9
+        r10 = A.solve_batch(A.AscentParams(), 2000, tol=1e-10, scheme=2, terminal="ellipse", max_iter=500)
+        assert r10.status[0] == 0 and abs(r10.tf[0] - by[(2000, 2, "periapsis")]["tf"]) <= 1e-9
+        assert abs(r.tf[0] - r10.tf[0]) < 1e-7
 
 
 def test_ellipse_terminal_through_the_hand_tuned_kernels(coracle):
@@ -236,3 +240,40 @@ def test_coast_arc_against_the_closed_form():
     Xe, Ye = c["traj"][0, -1] * Sx, c["traj"][1, -1] * Sx + R0
     assert np.abs(np.hypot(Xe, Ye) - a * (1 + e)).max() < 1e-4
     assert np.abs(c["traj"][:, 0, :] - st).max() < 1e-9
+
+
+def test_pcr_newton_variant_and_small_batch_dispatch(coracle, monkeypatch):
+    """The dense-block path solves its Newton systems by the serial Riccati recursion (one wavefront per NLP) or by
+    parallel cyclic reduction over the collocation nodes (one wavefront per node, 15x15 blocks on MFMA FP64 tiles;
+    ASCENT_DENSE_NEWTON=riccati|pcr, automatic: PCR up to 64 NLPs).  Same Newton step to rounding; same iterates, so the
+    same iteration counts and answers -- also the oracle's.  Batches of up to 8 NLPs of schemes 0/1 are routed to the
+    dense-block path with PCR automatically (ASCENT_SMALL_BATCH=off keeps the hand-tuned kernels): all three agree."""
+    nt = 40
+    S = A.sweep_isp_drymass(2, 2)
+    blobs = _interior_blobs(coracle, S, nt, 2)
+    mu = np.array([0.1, 0.02, 1e-3, 0.05]); dw = np.array([0.0, 1e-4, 1e-2, 1.0])
+    steps = {}
+    for mode in ("riccati", "pcr"):
+        monkeypatch.setenv("ASCENT_DENSE_NEWTON", mode)
+        steps[mode] = A.kkt_step(S, blobs, mu, dw, nt, path="dense", scheme=2)
+    assert np.array_equal(steps["riccati"][1], steps["pcr"][1]) and not steps["pcr"][1].any()
+    assert np.abs(steps["riccati"][0] - steps["pcr"][0]).max() <= 1e-10 * np.abs(steps["riccati"][0]).max()
+    for B, ntf, scheme in ((1, 200, 0), (5, 200, 1), (3, 200, 2), (1, 1000, 0), (9, 60, 0)):
+        P = np.vstack([A.AscentParams().as_row()[None], A.sweep_isp_drymass(3, 3)])[:B]
+        res = {}
+        for name, env in (("pcr", {"ASCENT_DENSE_NEWTON": "pcr"}), ("riccati", {"ASCENT_DENSE_NEWTON": "riccati"}),
+                          ("auto", {}), ("hand", {"ASCENT_SMALL_BATCH": "off"})):
+            monkeypatch.delenv("ASCENT_DENSE_NEWTON", raising=False); monkeypatch.delenv("ASCENT_SMALL_BATCH", raising=False)
+            for k_, v_ in env.items():
+                monkeypatch.setenv(k_, v_)
+            if name == "hand" and scheme == 2:
+                continue
+            res[name] = A.solve_batch(P, ntf, tol=1e-9, scheme=scheme, max_iter=500, path="dense" if name in ("pcr", "riccati") else "auto")
+            assert np.all(res[name].status == 0)
+        for name in res:
+            assert np.array_equal(res[name].iters, res["pcr"].iters), (B, ntf, scheme, name)
+            assert np.abs(res[name].tf - res["pcr"].tf).max() <= 1e-11
+        if scheme < 2:
+            ref = coracle.solve_batch(P, ntf, 500, 1e-9, scheme=scheme)
+            coracle.set_scheme(0)
+            assert np.abs(res["auto"].tf - ref["tf"]).max() <= 1e-9 and np.abs(res["auto"].iters.astype(int) - ref["iters"]).max() <= 1
