@@ -5,8 +5,8 @@ A "step" = one pass of the hot path over one batch per GPU: `batch_per_gpu` inde
 solved from the built-in cold start to KKT error <= tol, parameters already resident in HBM, results
 left in HBM, then the single result gather (tf, status, iters) to rank 0.
 Workload at N=1: BASELINE.json configs[2] -- the 4096-NLP Isp x dry-mass sweep.
-With N ranks (weak scaling) rank r solves the same 64x64 grid for its own target apoapsis, i.e. a
-slice of the config-4 grid; --batch-per-gpu 32768 with --gpus 8 is config 4 itself.
+With N ranks (weak scaling) every rank solves that same sweep, so the N=1 and N=8 lines time the same per-GPU work;
+--batch-per-gpu 32768 with --gpus 8 is config 4 itself (rank r = its contiguous shard of the 262 144-problem box).
 
 Prints ONE JSON line (rank 0).  `roofline.achieved` = algorithmic HBM bytes of the solve kernel
 (SURVEY.md 8d: B_alg = B_io + I*B_iter per NLP, I = iterations actually taken) / its HIP-event time;
@@ -57,8 +57,19 @@ def rank_params(batch: int, rank: int, world: int) -> np.ndarray:
     n = int(round(batch ** 0.5))
     while batch % n:
         n -= 1
-    base = A.AscentParams() if rank == 0 else A.AscentParams(r_apo=float(APO_KM[rank % 8]) * 1e3)
-    return A.sweep_isp_drymass(n, batch // n, base=base)       # 4096 -> the 64 x 64 grid of config 3
+    return A.sweep_isp_drymass(n, batch // n)       # 4096 -> the 64 x 64 grid of config 3, the same on every rank
+
+
+def source_sha16() -> str:
+    """Fingerprint of the kernel sources: ties a PMC traffic measurement to the build it was made on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "lunar_module_ascent_trajectory_optimiser_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hip", ".hpp")):
+            h.update(open(os.path.join(d, fn), "rb").read())
+    h.update(open(os.path.join(ROOT, "include", "ascent.h"), "rb").read())
+    return h.hexdigest()[:16]
 
 
 def usable_cores() -> int:
@@ -152,13 +163,19 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    for _ in range(args.warmup):
+    conv_steps = torch.zeros((), dtype=torch.int64, device=dev)   # converged NLPs summed over the timed steps (counted on the device)
+    for _ in range(max(args.warmup, 1) if args.warmup else 0):
         step()
+        conv_steps += (out["status"] == 0).sum()                  # (also warms up torch's own reduction kernel)
+    if not args.warmup:
+        conv_steps += torch.zeros((), dtype=torch.int64, device=dev)
+    conv_steps.zero_()
     barrier()
     kernel_ms = []
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
+        conv_steps += (out["status"] == 0).sum()
         kernel_ms.append(A.last_kernel_ms(local))          # HIP events on the launch stream (waits for the kernel)
     barrier()
     elapsed = time.perf_counter() - t0
@@ -170,11 +187,11 @@ def main():
     iters = out["iters"].cpu().numpy()
     status = out["status"].cpu().numpy()
     conv_local = int((status == 0).sum())
-    conv_total = conv_local
+    conv_total, conv_all_steps = conv_local, int(conv_steps.item())
     if dist:
-        t = torch.tensor([conv_local], dtype=torch.float64, device=cdev)
+        t = torch.tensor([conv_local, conv_all_steps], dtype=torch.float64, device=cdev)
         dist.all_reduce(t)
-        conv_total = int(t.item())
+        conv_total, conv_all_steps = int(t[0].item()), int(t[1].item())
     if rank == 0:
         k_ms = float(np.mean(kernel_ms))
         # iterations per grid level: `iters` counts both levels of the nested iteration; an untimed solve of the coarse
@@ -186,14 +203,17 @@ def main():
         b_alg = algorithmic_bytes(levels, len(iters), NT)
         f_alg = algorithmic_flops(levels)
         achieved = b_alg / (k_ms * 1e-3) / 1e9
+        # HBM bytes per solve from the PMC counters (profiles/traffic.json, made by scripts/traffic_from_pmc.py): only if that
+        # file was measured on THIS build of the kernels (hash of the csrc sources), otherwise null
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.exists(tpath):
-            tj = json.load(open(tpath))
-            traffic = tj.get(f"batch{B}", {}).get("hbm_bytes_per_launch")
+            tj = json.load(open(tpath)).get(f"batch{B}", {})
+            if tj.get("source_sha16") == source_sha16():
+                traffic = tj.get("hbm_bytes_per_launch")
         line = {
             "metric": "solved ascent NLPs/sec (N=200 collocation nodes)",
-            "value": conv_total * args.steps / elapsed,
+            "value": conv_all_steps / elapsed,
             "unit": "NLPs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3,
@@ -208,7 +228,8 @@ def main():
                 "parallelism": f"problem-sharded x{world}, gather only",
                 "iterations_min_mean_max": [int(iters.min()), float(iters.mean()), int(iters.max())],
                 "iterations_mean_by_grid": {str(NT): float((iters - it_c).mean()), str(ntc): float(it_c.mean())},
-                "converged": conv_total, "of": B * world,
+                "converged": conv_total, "of": B * world, "converged_over_all_timed_steps": conv_all_steps,
+                "kernel_source_sha16": source_sha16(),
             },
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

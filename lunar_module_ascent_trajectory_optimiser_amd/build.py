@@ -9,8 +9,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 ROOT = os.path.dirname(HERE)
 LIB = os.path.join(CSRC, "libascent.so")
-SOURCES = ["ascent_solver.hip", "ascent_pipeline.hip", "ascent_dense.hip", "ascent_blocktri.hip"]
-HEADERS = ["ascent_device.hpp", "ascent_tile.hpp", "ascent_pipeline.hpp", "ascent_dense.hpp", "ascent_blocktri.hpp", os.path.join(ROOT, "include", "ascent.h")]
+SOURCES = ["ascent_solver.hip", "ascent_pipeline.hip", "ascent_dense.hip", "ascent_blocktri.hip", "ascent_persist.hip"]
+HEADERS = ["ascent_device.hpp", "ascent_tile.hpp", "ascent_pipeline.hpp", "ascent_dense.hpp", "ascent_blocktri.hpp", "ascent_persist.hpp", os.path.join(ROOT, "include", "ascent.h")]
 
 
 def needs_build() -> bool:

@@ -828,7 +828,7 @@ __global__ __launch_bounds__(WAVE) void d_newton(const ascent_params *params, lo
 // UNKNOWNS (states, control, multipliers): the diagonal block then starts with the step Jacobian Jb ~ I, so the
 // unpivoted Gauss-Jordan inverse of ascent_blocktri meets unit-size pivots (in the symmetric order the leading block
 // would be the Lagrangian Hessian, which is tiny and indefinite).  PCR exposes no inertia; this variant regularises on
-// the curvature dx'(W + Sigma + delta)dx the merit function needs anyway (the rule of oracle/-side numpy restatement).
+// the curvature dx'(W + Sigma + delta)dx along the step, which the merit function needs anyway.
 // ==============================================================================================================
 constexpr int PC_NB = 2, PC_BS = 15;
 __global__ __launch_bounds__(WAVE) void pc_assemble(const ascent_params *params, long batch, DGeo g, const double *ws, double *bt,

@@ -1,0 +1,982 @@
+// Persistent solver kernel of the batched ascent NLP solver for medium batches (gfx950): ONE launch per grid level, one
+// wavefront owns four NLPs for the whole interior-point solve.
+//
+// The split pipeline (ascent_pipeline.hip) runs an interior-point iteration as five launches; the Jacobian / Hessian blocks
+// of every collocation node (/root/reference/Launch_Optimiser.py:114-136) are materialised in HBM by one kernel and read
+// back by four others (55 rows per node and iteration, 8.8x the algorithmic bytes at batch 4096), and the host steers
+// the rounds.  Here a wavefront keeps its four NLPs from the initial point to convergence:
+//   * the serial sweeps are the 16-lanes-per-NLP sweeps of the split pipeline (lanes 0-6 one column each of the 7x7
+//     value function, lanes 7-9 the three right-hand sides; DPP row broadcasts, LDS transposes);
+//   * the node-parallel work -- trial point, defects, Jacobian / Hessian blocks, merit and KKT-error pieces, bound-multiplier
+//     steps, adjoint right-hand sides -- is done by the SAME wavefront, 64 lanes = 4 NLPs x 16 consecutive nodes, one
+//     16-node chunk at a time, and handed to the sweep through LDS: the blocks of a chunk are produced into LDS, consumed
+//     by the 16 serial steps of that chunk and overwritten by the next chunk.  They never reach HBM; phases that need them
+//     again (forward, adjoint) evaluate them again (FP64 issue is what a lone wavefront per SIMD has to spare);
+//   * HBM holds, per NLP and node, the two iterate buffers, the step and the ten feedback gains of the factorisation
+//     ([NLP][row][node], node contiguous: a chunk row of an NLP is one 128-byte line);
+//   * line-search rejections, inertia corrections and the barrier schedule are per-NLP state in LDS; wavefronts do not
+//     wait for one another and the host is not involved until the level is finished.
+// Backward Euler (the reference's NODES=2), current formulation; the other schemes keep the split pipeline.
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstdlib>
+
+#include "ascent.h"
+#include "ascent_device.hpp"
+#include "ascent_tile.hpp"
+#include "ascent_persist.hpp"
+
+using namespace ascent;
+
+namespace {
+
+constexpr int NPW = 4, CH = 16;                 // NLPs per wavefront, nodes per chunk
+constexpr int O_Z = 0, O_U = 7, O_L = 8, O_ZB = 15, NIT = 21;
+constexpr int R_IT = 0, R_ST = 2 * NIT, R_KA = 3 * NIT, R_K0 = R_KA + 7, NROWS = R_K0 + 3;      // rows of an NLP's node arrays
+// LDS stage rows (one chunk): blocks of the factorisation; the forward / adjoint phases reuse the area
+constexpr int S_G = 0, S_E = 8, S_H = 12, S_F = 22, S_C = 29, S_RZ = 36, S_GT = 43, S_SC = 50, S_ROWS = 55;
+constexpr int S_KA = 36, S_K0 = 43;             // forward phase: gains (loaded from HBM) where the factor phase keeps rz / gt
+constexpr int S_R = 12;                         // adjoint phase: right-hand side where the factor phase keeps H
+constexpr int LDW = 65;                         // row stride in doubles: odd, so that the 16 rows a sweep step gathers hit 16 banks
+constexpr int OUT_ROWS = 11;
+enum {
+  X_STATE, X_ITERS, X_STATUS, X_CUR, X_FIRST, X_LS, X_MU, X_NUP, X_DW, X_DWL, X_ALPHA, X_ADU, X_PHI0, X_DM, X_C1, X_SL,
+  X_RTH, X_DTH, X_DNU3, X_SIG1, X_SIG2, X_RS1, X_RS2, X_CG1, X_CG2,
+  X_S,                       // 10 scalars of the iterate
+  X_T = X_S + 10,            // 10 trial scalars
+  X_D = X_T + 10,            // 10 step scalars
+  NSCAL = X_D + 10
+};
+enum { ST_TRIAL = 0, ST_FACTOR = 1, ST_FACTORED = 2, ST_DONE = 3 };
+
+struct PGeo {
+  int K, Kp, nch;
+  __host__ __device__ size_t nlp_doubles() const { return (size_t)NROWS * Kp + NSCAL; }
+};
+
+template <int SRC>
+ASC_DEV double bcast16(double v) {
+  const long x = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(long, v), 0x150 + SRC, 0xf, 0xf, false);
+  return __builtin_bit_cast(double, x);
+}
+template <int N>
+struct OneHot {
+  double m[N];
+  ASC_DEV explicit OneHot(int role) {
+    ASC_UNROLL
+    for (int i = 0; i < N; i++) m[i] = (role == i || (i == 0 && role >= N)) ? 1.0 : 0.0;
+  }
+  ASC_DEV double pick(const double *v) const {
+    double r = m[0] * v[0];
+    ASC_UNROLL
+    for (int i = 1; i < N; i++) r += m[i] * v[i];
+    return r;
+  }
+};
+ASC_DEV void wsync() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+// reductions over the 16 lanes of an NLP (xor strides stay inside the row of 16)
+ASC_DEV double gsum16(double v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); return v; }
+ASC_DEV double gmax16(double v) { v = fmax(v, __shfl_xor(v, 1)); v = fmax(v, __shfl_xor(v, 2)); v = fmax(v, __shfl_xor(v, 4)); return fmax(v, __shfl_xor(v, 8)); }
+ASC_DEV double gmin16(double v) { v = fmin(v, __shfl_xor(v, 1)); v = fmin(v, __shfl_xor(v, 2)); v = fmin(v, __shfl_xor(v, 4)); return fmin(v, __shfl_xor(v, 8)); }
+
+ASC_DEV Scal lds_scal(const double *sc, int r0) {
+  Scal s;
+  s.th = sc[r0 + S_TH]; s.zlt = sc[r0 + S_ZLT]; s.zut = sc[r0 + S_ZUT]; s.s1 = sc[r0 + S_S1]; s.s2 = sc[r0 + S_S2];
+  s.zs1 = sc[r0 + S_ZS1]; s.zs2 = sc[r0 + S_ZS2]; s.nu3 = sc[r0 + S_NU3]; s.nu1 = sc[r0 + S_NU1]; s.nu2 = sc[r0 + S_NU2];
+  return s;
+}
+ASC_DEV void put_scal(double *sc, int r0, const Scal &s) {
+  sc[r0 + S_TH] = s.th; sc[r0 + S_ZLT] = s.zlt; sc[r0 + S_ZUT] = s.zut; sc[r0 + S_S1] = s.s1; sc[r0 + S_S2] = s.s2;
+  sc[r0 + S_ZS1] = s.zs1; sc[r0 + S_ZS2] = s.zs2; sc[r0 + S_NU3] = s.nu3; sc[r0 + S_NU1] = s.nu1; sc[r0 + S_NU2] = s.nu2;
+}
+ASC_DEV Scal trial_scal(const Der &d, const Scal &s, const Scal &ds, double alpha, double adu, double mu, bool first) {
+  Scal t = s;
+  if (first) return t;
+  t.th += alpha * ds.th; t.s1 += alpha * ds.s1; t.s2 += alpha * ds.s2;
+  t.nu3 += alpha * ds.nu3; t.nu1 += alpha * ds.nu1; t.nu2 += alpha * ds.nu2;
+  t.zlt = clipz(s.zlt + adu * ds.zlt, t.th - d.tlb, mu);
+  t.zut = clipz(s.zut + adu * ds.zut, d.tub - t.th, mu);
+  t.zs1 = clipz(s.zs1 + adu * ds.zs1, t.s1, mu);
+  t.zs2 = clipz(s.zs2 + adu * ds.zs2, t.s2, mu);
+  return t;
+}
+
+// ==============================================================================================================
+// p_init / p_finish: external blob layouts <-> [NLP][row][node].  Lane = (NLP, node).
+// ==============================================================================================================
+__global__ __launch_bounds__(WAVE) void p_init(const ascent_params *params, long batch, PGeo g, double *ws, const double *guess,
+                                               int warm, double mu_init) {
+  const long p = blockIdx.y;
+  const int k = blockIdx.x * WAVE + threadIdx.x, K = g.K, Kp = g.Kp;
+  if (k >= Kp) return;
+  double *w = ws + (size_t)p * g.nlp_doubles();
+  const Der d = derive(params[p]);
+  const int asked_warm = warm;
+  if (warm && !(guess[(21L * K + S_TH) * batch + p] > 0.0)) warm = 0;
+  const double tf0 = 0.9, dr = 0.166, aend = 0.5, vp = sqrt(d.vp2), dt0 = (1.0 / K) * d.T * tf0;
+  const double sdr = sin(dr), cdr = cos(dr);
+  const double xf = -d.rhof * sdr, yf = d.rhof * cdr - d.rho0;
+  double z[7], l[7], zb[6], u;
+  const int kk = k < K ? k : K - 1;                  // padding nodes replicate the last node (never read by anything that counts)
+  if (warm) {
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) { z[i] = guess[(7L * kk + i) * batch + p]; l[i] = guess[(8L * K + 7L * kk + i) * batch + p]; }
+    u = guess[(7L * K + kk) * batch + p];
+    ASC_UNROLL
+    for (int b = 0; b < 6; b++) zb[b] = guess[(15L * K + 6L * kk + b) * batch + p];
+  } else {
+    const double fr = (double)(kk + 1) / K;
+    z[IX] = fr * xf; z[IY] = fr * yf; z[IVX] = -fr * vp * cdr; z[IVY] = -fr * vp * sdr; z[IA] = fr * aend;
+    z[IW] = aend / (K * dt0); z[IM] = d.mrate * dt0 * (kk + 1);
+    u = 0.0;
+  }
+  z[IA] = push_in(z[IA], 0.0, d.aub);
+  z[IM] = push_in(z[IM], 0.0, 1.0);
+  u = push_in(u, -1.0, 1.0);
+  ASC_UNROLL
+  for (int b = 0; b < 6; b++) zb[b] = warm == 2 ? fmax(zb[b], 1e-12) : 1.0;
+  ASC_UNROLL
+  for (int i = 0; i < 7; i++) l[i] = warm == 2 ? l[i] : 0.0;
+  ASC_UNROLL
+  for (int i = 0; i < 7; i++) { w[(R_IT + O_Z + i) * Kp + k] = z[i]; w[(R_IT + O_L + i) * Kp + k] = l[i]; }
+  w[(R_IT + O_U) * Kp + k] = u;
+  ASC_UNROLL
+  for (int b = 0; b < 6; b++) w[(R_IT + O_ZB + b) * Kp + k] = zb[b];
+  for (int r = NIT; r < NROWS; r++) w[(size_t)r * Kp + k] = 0.0;          // second iterate buffer, step, gains
+  if (k != K - 1) return;
+  double *sc = w + (size_t)NROWS * Kp;
+  Scal s;
+  if (warm) {
+    const double *gs = guess + (21L * K) * batch + p;
+    s.th = gs[S_TH * batch]; s.zlt = gs[S_ZLT * batch]; s.zut = gs[S_ZUT * batch]; s.s1 = gs[S_S1 * batch];
+    s.s2 = gs[S_S2 * batch]; s.zs1 = gs[S_ZS1 * batch]; s.zs2 = gs[S_ZS2 * batch]; s.nu3 = gs[S_NU3 * batch];
+    s.nu1 = gs[S_NU1 * batch]; s.nu2 = gs[S_NU2 * batch];
+  } else {
+    s.th = tf0;
+  }
+  s.th = push_in(s.th, d.tlb, d.tub);
+  const Terminal tm = terminal_eval(d, z);
+  if (warm != 2) {
+    s.s1 = fmax(tm.g1, 1e-2); s.s2 = fmax(tm.g2, 1e-2);
+    s.zlt = s.zut = s.zs1 = s.zs2 = 1.0;
+    s.nu3 = s.nu1 = s.nu2 = 0.0;
+  } else {
+    s.s1 = fmax(s.s1, 1e-10); s.s2 = fmax(s.s2, 1e-10);
+    s.zlt = fmax(s.zlt, 1e-12); s.zut = fmax(s.zut, 1e-12);
+    s.zs1 = fmax(s.zs1, 1e-12); s.zs2 = fmax(s.zs2, 1e-12);
+  }
+  for (int r = 0; r < NSCAL; r++) sc[r] = 0.0;
+  put_scal(sc, X_S, s);
+  sc[X_STATE] = ST_TRIAL; sc[X_FIRST] = 1.0; sc[X_STATUS] = ASCENT_MAX_ITER;
+  sc[X_MU] = (asked_warm && !warm) ? 0.1 : mu_init; sc[X_NUP] = 1.0;
+}
+
+__global__ __launch_bounds__(WAVE) void p_finish(const ascent_params *params, long batch, PGeo g, const double *ws, double *traj,
+                                                 double *tf_out, int *status_out, int *iters_out, double *blob) {
+  const long p = blockIdx.y;
+  const int k = blockIdx.x * WAVE + threadIdx.x, K = g.K, Kp = g.Kp, nt = K + 1;
+  if (k >= K) return;
+  const double *w = ws + (size_t)p * g.nlp_doubles();
+  const double *sc = w + (size_t)NROWS * Kp;
+  const Der d = derive(params[p]);
+  const double *it = w + (size_t)((int)sc[X_CUR] * NIT) * Kp;
+  if (k == 0) {
+    const Scal s = lds_scal(sc, X_S);
+    tf_out[p] = s.th;
+    status_out[p] = (int)sc[X_STATUS];
+    iters_out[p] = (int)sc[X_ITERS];
+    if (blob) {
+      double *bs = blob + (21L * K) * batch + p;
+      bs[S_TH * batch] = s.th; bs[S_ZLT * batch] = s.zlt; bs[S_ZUT * batch] = s.zut; bs[S_S1 * batch] = s.s1;
+      bs[S_S2 * batch] = s.s2; bs[S_ZS1 * batch] = s.zs1; bs[S_ZS2 * batch] = s.zs2; bs[S_NU3 * batch] = s.nu3;
+      bs[S_NU1 * batch] = s.nu1; bs[S_NU2 * batch] = s.nu2;
+    }
+    if (traj) {
+      double ax, ay;
+      accel<0>(d, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, ax, ay, nullptr, nullptr);
+      const double v[10] = {0.0, 0.0, 0.0, 0.0, ax, ay, 0.0, 0.0, 0.0, 0.0};
+      ASC_UNROLL
+      for (int f = 0; f < 10; f++) traj[((long)f * nt) * batch + p] = v[f];
+    }
+  }
+  double z[7];
+  ASC_UNROLL
+  for (int q = 0; q < 7; q++) z[q] = it[(O_Z + q) * Kp + k];
+  const double u = it[O_U * Kp + k];
+  if (blob) {
+    ASC_UNROLL
+    for (int q = 0; q < 7; q++) {
+      blob[(7L * k + q) * batch + p] = z[q];
+      blob[(8L * K + 7L * k + q) * batch + p] = it[(O_L + q) * Kp + k];
+    }
+    blob[(7L * K + k) * batch + p] = u;
+    ASC_UNROLL
+    for (int b = 0; b < 6; b++) blob[(15L * K + 6L * k + b) * batch + p] = it[(O_ZB + b) * Kp + k];
+  }
+  if (traj) {
+    double ax, ay;
+    accel<0>(d, z[IX], z[IY], z[IA], z[IM], 0.0, 0.0, ax, ay, nullptr, nullptr);
+    const double v[10] = {z[IX], z[IY], z[IVX], z[IVY], ax, ay, z[IA], z[IW], u, z[IM]};
+    ASC_UNROLL
+    for (int f = 0; f < 10; f++) traj[((long)f * nt + k + 1) * batch + p] = v[f];
+  }
+}
+
+// ==============================================================================================================
+// p_solve: the whole interior-point loop of one grid level
+// ==============================================================================================================
+struct NodeIn {      // what a node evaluation reads: node k of the iterate, the state of node k-1, the multipliers of node k+1
+  double z[7], zp[7], l[7], ln[7], zb[6], u;
+};
+ASC_DEV void load_node(const double *it, int Kp, int K, int k, NodeIn &n) {
+  ASC_UNROLL
+  for (int i = 0; i < 7; i++) {
+    n.z[i] = it[(O_Z + i) * Kp + k];
+    n.l[i] = it[(O_L + i) * Kp + k];
+    n.zp[i] = k > 0 ? it[(O_Z + i) * Kp + k - 1] : 0.0;
+    n.ln[i] = k + 1 < K ? it[(O_L + i) * Kp + k + 1] : 0.0;
+  }
+  n.u = it[O_U * Kp + k];
+  ASC_UNROLL
+  for (int b = 0; b < 6; b++) n.zb[b] = it[(O_ZB + b) * Kp + k];
+}
+
+#ifdef PERSIST_PROFILE      // diagnostic build (scripts/persist_profile.py): shader cycles per phase, wavefront 0
+#define PROF_DECL long long prof_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long pt_ = clock64();
+#define PROF(i_) do { const long long t1_ = clock64(); prof_[i_] += t1_ - pt_; pt_ = t1_; } while (0)
+#define PROF_END do { if (blockIdx.x == 0 && threadIdx.x == 0) printf("[persist profile] cycles: A %lld | B eval %lld serial %lld flush %lld | F eval %lld serial %lld post %lld | Adj eval %lld serial %lld | rest %lld\n", prof_[0], prof_[1], prof_[2], prof_[3], prof_[4], prof_[5], prof_[6], prof_[7], prof_[8], prof_[9]); } while (0)
+#else
+#define PROF_DECL
+#define PROF(i_) do { } while (0)
+#define PROF_END do { } while (0)
+#endif
+
+__global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, long batch, PGeo g, double *ws, int max_iter, double tol) {
+  __shared__ double stage[S_ROWS * LDW];
+  __shared__ double outb[OUT_ROWS * LDW];
+  __shared__ double lds_t[NPW][7][7];
+  __shared__ double lds_d[NPW][2][8];
+  __shared__ double lsc[NPW][NSCAL];
+  const int lane = threadIdx.x, grp = lane >> 4, role = lane & 15;
+  const long p = (long)blockIdx.x * NPW + grp;
+  const bool live = p < batch;
+  const long pc = live ? p : batch - 1;                 // dead groups shadow the last NLP and never store
+  const int K = g.K, Kp = g.Kp, nch = g.nch;
+  double *w = ws + (size_t)pc * g.nlp_doubles();
+  double *gsc = w + (size_t)NROWS * Kp;
+  double *sc = lsc[grp];
+  const Der d = derive(params[pc]);
+  for (int r = role; r < NSCAL; r += 16) sc[r] = gsc[r];
+  wsync();
+  if (!live && role == 0) sc[X_STATE] = ST_DONE;
+  wsync();
+  const int col = grp * 16 + role;                      // this lane's column of the LDS stage in node-parallel phases
+  const double hT = (1.0 / K) * d.T;
+  constexpr int IB = IW;
+
+  PROF_DECL
+  for (int round = 0; round < 64 * (max_iter + 2); round++) {
+    PROF(9);
+    // ============================ A: trial point, merit function and KKT error ======================================
+    int state = (int)sc[X_STATE];
+    if (__all(state == ST_DONE)) break;
+    if (state == ST_TRIAL) {
+      const bool first = sc[X_FIRST] != 0.0;
+      const double alpha = first ? 0.0 : sc[X_ALPHA], adu = first ? 0.0 : sc[X_ADU], mu = sc[X_MU];
+      const Scal s = lds_scal(sc, X_S), ds = lds_scal(sc, X_D);
+      const Scal stt = trial_scal(d, s, ds, alpha, adu, mu, first);
+      const int cur = (int)sc[X_CUR];
+      const double *ic = w + (size_t)(cur * NIT) * Kp, *stp = w + (size_t)R_ST * Kp;
+      double *in = w + (size_t)((1 - cur) * NIT) * Kp;
+      const double dt = hT * stt.th, be = dt * d.alpha;
+      const double mlo = mu * 1e-10, mhi = mu * 1e10;
+      double rd = 0.0, cinf = 0.0, pmin = 1e300, pmax = -1e300, l1 = 0.0, zsum = 0.0, rth = 0.0, c1 = 0.0, sl = 0.0;
+#ifdef PERSIST_DEBUG
+      double dbg_stepl = 0.0;
+#endif
+      for (int c = 0; c < nch; c++) {
+        const int k = c * CH + role;
+        if (k < K) {
+          NodeIn n, dn;
+          load_node(ic, Kp, K, k, n);
+          load_node(stp, Kp, K, k, dn);
+#ifdef PERSIST_DEBUG
+          for (int i = 0; i < 7; i++) dbg_stepl = fmax(dbg_stepl, fabs(dn.l[i]));
+#endif
+          double z[7], zp[7], l[7], ln[7], zb[6];
+          ASC_UNROLL
+          for (int i = 0; i < 7; i++) {
+            z[i] = n.z[i] + alpha * dn.z[i]; zp[i] = n.zp[i] + alpha * dn.zp[i];
+            l[i] = n.l[i] + alpha * dn.l[i]; ln[i] = n.ln[i] + alpha * dn.ln[i];
+          }
+          const double u = n.u + alpha * dn.u;
+          const double dist[6] = {z[IA], d.aub - z[IA], z[IM], 1.0 - z[IM], u + 1.0, 1.0 - u};
+          ASC_UNROLL
+          for (int b = 0; b < 6; b++) {
+            const double id = rcp(dist[b]);
+            zb[b] = first ? n.zb[b] : fmin(fmax(n.zb[b] + adu * dn.zb[b], mlo * id), mhi * id);
+          }
+          if (live) {
+            ASC_UNROLL
+            for (int i = 0; i < 7; i++) { in[(O_Z + i) * Kp + k] = z[i]; in[(O_L + i) * Kp + k] = l[i]; }
+            in[O_U * Kp + k] = u;
+            ASC_UNROLL
+            for (int b = 0; b < 6; b++) in[(O_ZB + b) * Kp + k] = zb[b];
+          }
+          double G[8], F[7], fl[7], ax, ay;
+          accel<1>(d, z[IX], z[IY], z[IA], z[IM], 0.0, 0.0, ax, ay, G, nullptr);
+          rhs_f(d, z, u, ax, ay, F);
+          fzt_lambda(G, l, fl);
+          double r[7];
+          ASC_UNROLL
+          for (int i = 0; i < 7; i++) {
+            r[i] = l[i] - dt * fl[i] - ln[i];
+            const double cc = z[i] - zp[i] - dt * F[i];
+            c1 += fabs(cc);
+            cinf = fmax(cinf, fabs(cc));
+            rth -= hT * F[i] * l[i];
+            l1 += fabs(l[i]);
+          }
+          r[IA] += zb[1] - zb[0];
+          r[IM] += zb[3] - zb[2];
+          if (k == K - 1) {
+            const Terminal t = terminal_eval(d, z);
+            r[IX] += stt.nu3 * t.e3g[0] + stt.nu1 * t.g1g[0];
+            r[IY] += stt.nu3 * t.e3g[1] + stt.nu1 * t.g1g[1];
+            r[IVX] += stt.nu3 * t.e3g[2] + stt.nu2 * t.g2g[0];
+            r[IVY] += stt.nu3 * t.e3g[3] + stt.nu2 * t.g2g[1];
+            const double e1 = fabs(t.e3), e2 = fabs(t.g1 - stt.s1), e3 = fabs(t.g2 - stt.s2);
+            cinf = fmax(cinf, fmax(e1, fmax(e2, e3)));
+            c1 += e1 + e2 + e3;
+            const double ps = ((stt.th - d.tlb) * (d.tub - stt.th)) * (stt.s1 * stt.s2);
+            sl += ps > 0.0 ? log(ps) : NAN;
+          }
+#ifdef PERSIST_DEBUG
+          if (blockIdx.x == 0 && grp == 0 && sc[X_ITERS] == 20.0) {
+            for (int i = 0; i < 7; i++) if (fabs(r[i]) > 1e-6) printf("[persist]      trial node %d field %d r %.4e l %.6e fl %.6e ln %.6e dt %.4e zb %.3e %.3e %.3e %.3e\n", k, i, r[i], l[i], fl[i], ln[i], dt, zb[0], zb[1], zb[2], zb[3]);
+            if (fabs(-be * l[IB] - zb[4] + zb[5]) > 1e-6) printf("[persist]      trial node %d control row %.4e\n", k, -be * l[IB] - zb[4] + zb[5]);
+          }
+#endif
+          ASC_UNROLL
+          for (int i = 0; i < 7; i++) rd = fmax(rd, fabs(r[i]));
+          rd = fmax(rd, fabs(-be * l[IB] - zb[4] + zb[5]));
+          ASC_UNROLL
+          for (int b = 0; b < 6; b++) { const double pr = dist[b] * zb[b]; pmin = fmin(pmin, pr); pmax = fmax(pmax, pr); zsum += zb[b]; }
+          const double pa = dist[0] * dist[1], pm = dist[2] * dist[3], pu = dist[4] * dist[5];
+          sl += (pa > 0.0 && pm > 0.0 && pu > 0.0) ? log(pa * pm * pu) : NAN;
+        }
+      }
+#ifdef PERSIST_DEBUG
+      dbg_stepl = gmax16(dbg_stepl);
+      if (blockIdx.x == 0 && lane == 0) printf("[persist]    trial: alpha %.3g cur %d max|dlam read| %.3e first %d\n", alpha, cur, dbg_stepl, (int)first);
+#endif
+      rd = gmax16(rd); cinf = gmax16(cinf); pmin = gmin16(pmin); pmax = gmax16(pmax);
+      l1 = gsum16(l1); zsum = gsum16(zsum); rth = 1.0 + gsum16(rth); c1 = gsum16(c1); sl = gsum16(sl);
+      // ---- decisions (all 16 lanes of the NLP alike; lane 0 writes) -------------------------------------------------
+      double nu_pen = sc[X_NUP], iters = sc[X_ITERS], mu2 = mu;
+      int nstate = ST_FACTOR;
+      bool accepted = true;
+      if (!first) {
+        const double phi0 = sc[X_PHI0], Dm = sc[X_DM];
+        const double phit = stt.th - mu * sl + nu_pen * c1;
+#ifdef PERSIST_DEBUG
+        if (blockIdx.x == 0 && lane == 0) printf("[persist] it %d alpha %.4g adu %.4g mu %.2e phit %.17g phi0 %.17g Dm %.3e c1 %.3e sl %.12g nu %.3g ls %d\n", (int)iters, alpha, adu, mu, phit, phi0, Dm, c1, sl, nu_pen, (int)sc[X_LS]);
+#endif
+        if (!(isfinite(phit) && phit <= phi0 + 1e-8 * alpha * Dm + 2.220446049250313e-15 * fabs(phi0))) {
+          accepted = false;
+          const int ls = (int)sc[X_LS] + 1;
+          wsync();
+          if (role == 0) {
+            sc[X_LS] = ls;
+            if (ls >= 40) { sc[X_STATUS] = ASCENT_LINESEARCH_FAILED; sc[X_STATE] = ST_DONE; }
+            else sc[X_ALPHA] = 0.5 * alpha;
+          }
+        } else {
+          iters += 1.0;
+        }
+      }
+      if (accepted) {
+        ErrParts e;
+        e.rd = fmax(rd, fabs(rth - stt.zlt + stt.zut));
+        e.rd = fmax(e.rd, fmax(fabs(-stt.nu1 - stt.zs1), fabs(-stt.nu2 - stt.zs2)));
+        e.cinf = cinf;
+        const double pr[4] = {(stt.th - d.tlb) * stt.zlt, (d.tub - stt.th) * stt.zut, stt.s1 * stt.zs1, stt.s2 * stt.zs2};
+        ASC_UNROLL
+        for (int q = 0; q < 4; q++) { pmin = fmin(pmin, pr[q]); pmax = fmax(pmax, pr[q]); }
+        e.pmin = pmin; e.pmax = pmax;
+        l1 += fabs(stt.nu3) + fabs(stt.nu1) + fabs(stt.nu2);
+        zsum += stt.zlt + stt.zut + stt.zs1 + stt.zs2;
+        e.sd = fmax(100.0, (l1 + zsum) / (double)(13 * K + 7)) * 0.01;
+        int status = -1;
+#ifdef PERSIST_DEBUG
+        if (blockIdx.x == 0 && lane == 0) printf("[persist]    node rd %.3e | th %.3e | s1 %.3e s2 %.3e | dw_last %.2e state dw %.2e\n", rd, fabs(rth - stt.zlt + stt.zut), fabs(-stt.nu1 - stt.zs1), fabs(-stt.nu2 - stt.zs2), sc[X_DWL], sc[X_DW]);
+        if (blockIdx.x == 0 && lane == 0) printf("[persist]    accepted it %d: E0 %.3e (rd %.3e cinf %.3e pmin %.3e pmax %.3e sd %.3e) rth-res %.3e mu %.1e\n", (int)iters, e.err(0.0), e.rd, e.cinf, e.pmin, e.pmax, e.sd, fabs(rth - stt.zlt + stt.zut), mu);
+#endif
+        if (e.err(0.0) <= tol) { status = ASCENT_CONVERGED; nstate = ST_DONE; }
+        else if ((int)iters >= max_iter) { status = ASCENT_MAX_ITER; nstate = ST_DONE; }
+        else {
+          while (mu2 > tol * 0.1 && e.err(mu2) <= 10.0 * mu2) {
+            mu2 = fmax(tol * 0.1, fmin(0.2 * mu2, mu2 * sqrt(mu2)));
+            nu_pen = 1.0;
+          }
+        }
+        wsync();
+        if (role == 0) {
+          put_scal(sc, X_S, stt);
+          sc[X_CUR] = 1 - cur; sc[X_FIRST] = 0.0; sc[X_ITERS] = iters; sc[X_LS] = 0.0; sc[X_C1] = c1; sc[X_SL] = sl; sc[X_RTH] = rth;
+          sc[X_MU] = mu2; sc[X_NUP] = nu_pen; sc[X_DW] = 0.0; sc[X_STATE] = nstate;
+          if (status >= 0) sc[X_STATUS] = status;
+        }
+      }
+    }
+    wsync();
+    PROF(0);
+    // ============================ B: node blocks into LDS + backward factorisation ==================================
+    state = (int)sc[X_STATE];
+    if (__any(state == ST_FACTOR)) {
+      const bool act = state == ST_FACTOR;
+      const Scal s = lds_scal(sc, X_S);
+      const double mu = sc[X_MU], dw = sc[X_DW];
+      const double *it = w + (size_t)((int)sc[X_CUR] * NIT) * Kp;
+      const double dt = hT * s.th, be = dt * d.alpha, ith = rcp(s.th), cs = dt, bu = be;
+      // what this lane gathers from a step's blocks for row i of its vector (factor phase), as in q_factor_wide
+      int grow[7];
+      double gsgn[7];
+      {
+        constexpr int hmap[7] = {0, 1, -1, -1, 2, -1, 3};
+        constexpr int hrow[4][4] = {{0, 1, 2, 3}, {1, 4, 5, 6}, {2, 5, 7, 8}, {3, 6, 8, 9}};
+        ASC_UNROLL
+        for (int i = 0; i < 7; i++) {
+          int row = S_H; double sgn = 0.0;
+          if (role < 7) {
+            ASC_UNROLL
+            for (int c = 0; c < 7; c++)
+              if (c == role && hmap[i] >= 0 && hmap[c] >= 0) { row = S_H + hrow[hmap[i]][hmap[c]]; sgn = 1.0; }
+          } else if (role == 7) { row = S_RZ + i; sgn = -1.0; }
+          else if (role == 8) { row = S_GT + i; sgn = -1.0; }
+          grow[i] = row * LDW;
+          gsgn[i] = sgn;
+        }
+      }
+      const double bsc = role == 7 ? -mu : 0.0;
+      const int rowA = (role < 8 ? S_G + role : role < 12 ? S_E + role - 8 : role == 12 ? S_SC : role == 13 ? S_SC + 1
+                        : role == 14 ? S_SC + 4 : S_SC + 2) * LDW;
+      const int rowB = (role < 7 ? S_C + role : role < 14 ? S_F + role - 7 : role == 14 ? S_SC + 3 : S_SC) * LDW;
+      const int rowK = (role < 7 ? role : role < 10 ? role : 10) * LDW;      // out rows 0-6 kap, 7-9 k0, 10 dummy
+      const bool colr = role < 7, rhs = role >= 7 && role < 10;
+      double a[7];
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) a[i] = 0.0;
+      double U = 0.0, V = 0.0, k10 = 0.0, k11 = 0.0, k12 = 0.0, k20 = 0.0, k22 = 0.0;
+      int bad = 0;
+      double zK[7];
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) zK[i] = it[(O_Z + i) * Kp + K - 1];
+      const Terminal tm = terminal_eval(d, zK);
+      const double is1 = rcp(s.s1), is2 = rcp(s.s2);
+      const double sig1 = s.zs1 * is1 + dw, sig2 = s.zs2 * is2 + dw;
+      const double rs1 = -mu * is1 - s.nu1, rs2 = -mu * is2 - s.nu2;
+      {
+        const double cg1 = tm.g1 - s.s1, cg2 = tm.g2 - s.s2;
+        double Qt[28];
+        ASC_UNROLL
+        for (int i = 0; i < 28; i++) Qt[i] = 0.0;
+        terminal_hessian(Qt, tm, s.nu3, s.nu1, s.nu2, sig1, sig2);
+        const double w1 = s.nu1 + sig1 * cg1 + rs1, w2 = s.nu2 + sig2 * cg2 + rs2;
+        const double r0[4] = {s.nu3 * tm.e3g[0] + w1 * tm.g1g[0], s.nu3 * tm.e3g[1] + w1 * tm.g1g[1],
+                              s.nu3 * tm.e3g[2] + w2 * tm.g2g[0], s.nu3 * tm.e3g[3] + w2 * tm.g2g[1]};
+        ASC_UNROLL
+        for (int i = 0; i < 7; i++) {
+          double v = 0.0;
+          ASC_UNROLL
+          for (int c = 0; c < 7; c++) v = role == c ? Qt[sid(i, c)] : v;
+          if (i < 4) { v = role == 7 ? -r0[i] : v; v = role == 9 ? -tm.e3g[i] : v; }
+          a[i] = v;
+        }
+      }
+      for (int c = nch - 1; c >= 0; c--) {
+        // ---- node-parallel: the blocks of the 16 nodes of this chunk -------------------------------------------------
+        {
+          const int k = c * CH + role;
+          if (k < K && act) {
+            NodeIn n;
+            load_node(it, Kp, K, k, n);
+            double G[8], E[4], H[10], F[7], fl[7], ax, ay;
+            accel<2>(d, n.z[IX], n.z[IY], n.z[IA], n.z[IM], -cs * n.l[IVX], -cs * n.l[IVY], ax, ay, G, H);
+            rhs_f(d, n.z, n.u, ax, ay, F);
+            implicit_block(G, cs, E);
+            fzt_lambda(G, n.l, fl);
+            const double dist[6] = {n.z[IA], d.aub - n.z[IA], n.z[IM], 1.0 - n.z[IM], n.u + 1.0, 1.0 - n.u};
+            double id[6];
+            ASC_UNROLL
+            for (int b = 0; b < 6; b++) id[b] = rcp(dist[b]);
+            H[7] += n.zb[0] * id[0] + n.zb[1] * id[1];
+            H[9] += n.zb[2] * id[2] + n.zb[3] * id[3];
+            ASC_UNROLL
+            for (int i = 0; i < 8; i++) stage[(S_G + i) * LDW + col] = G[i];
+            ASC_UNROLL
+            for (int i = 0; i < 4; i++) stage[(S_E + i) * LDW + col] = E[i];
+            ASC_UNROLL
+            for (int i = 0; i < 10; i++) stage[(S_H + i) * LDW + col] = H[i];
+            ASC_UNROLL
+            for (int i = 0; i < 7; i++) {
+              stage[(S_F + i) * LDW + col] = F[i];
+              stage[(S_C + i) * LDW + col] = n.z[i] - n.zp[i] - dt * F[i];
+              stage[(S_RZ + i) * LDW + col] = n.l[i] - cs * fl[i] - n.ln[i];
+              stage[(S_GT + i) * LDW + col] = -hT * fl[i];
+            }
+            const double scr[5] = {n.zb[4] * id[4] + n.zb[5] * id[5], -be * n.l[IW], id[1] - id[0], id[3] - id[2], id[5] - id[4]};
+            ASC_UNROLL
+            for (int i = 0; i < 5; i++) stage[(S_SC + i) * LDW + col] = scr[i];
+          }
+        }
+        wsync();
+        PROF(1);
+        // ---- serial: the 16 steps of the chunk, backwards; 16 lanes per NLP (the arithmetic of q_factor_wide) -----------
+        if (act) {
+          for (int jj = CH - 1; jj >= 0; jj--) {
+            const int k = c * CH + jj;
+            if (k >= K) continue;
+            const int cj = grp * 16 + jj;
+            double gq[7];
+            ASC_UNROLL
+            for (int i = 0; i < 7; i++) gq[i] = stage[grow[i] + cj];
+            const double gA = stage[rowA + cj], gB = stage[rowB + cj];
+            const double G[8] = {bcast16<0>(gA), bcast16<1>(gA), bcast16<2>(gA), bcast16<3>(gA),
+                                 bcast16<4>(gA), bcast16<5>(gA), bcast16<6>(gA), bcast16<7>(gA)};
+            const double E[4] = {bcast16<8>(gA), bcast16<9>(gA), bcast16<10>(gA), bcast16<11>(gA)};
+            const double R0 = bcast16<12>(gA), ru0 = bcast16<13>(gA), bur = bcast16<14>(gA);
+            const double bza = bcast16<15>(gA), bzm = bcast16<14>(gB);
+            const double cc[7] = {bcast16<0>(gB), bcast16<1>(gB), bcast16<2>(gB), bcast16<3>(gB),
+                                  bcast16<4>(gB), bcast16<5>(gB), bcast16<6>(gB)};
+            const double rc1[7] = {hT * bcast16<7>(gB), hT * bcast16<8>(gB), hT * bcast16<9>(gB),
+                                   hT * bcast16<10>(gB), hT * bcast16<11>(gB), hT * bcast16<12>(gB),
+                                   hT * bcast16<13>(gB)};
+            ASC_UNROLL
+            for (int i = 0; i < 7; i++) a[i] += gsgn[i] * gq[i];
+            a[IA] += bsc * bza;
+            a[IM] += bsc * bzm;
+            if (dw != 0.0) {
+              ASC_UNROLL
+              for (int i = 0; i < 7; i++) a[i] += role == i ? dw : 0.0;
+            }
+            double b[7];
+            solveAT<0>(G, E, cs, a, b);
+            if (colr) {
+              ASC_UNROLL
+              for (int i = 0; i < 7; i++) lds_t[grp][role][i] = b[i];
+            }
+            wsync();
+            if (colr) {
+              double t[7];
+              ASC_UNROLL
+              for (int l2 = 0; l2 < 7; l2++) t[l2] = lds_t[grp][l2][role];
+              solveAT<0>(G, E, cs, t, b);
+            }
+            double mw[7];
+            ASC_UNROLL
+            for (int i = 0; i < 7; i++) mw[i] = bu * bcast16<IB>(b[i]);
+            const double D = R0 + dw + bu * mw[IB];
+            if (!(D > 0.0)) bad = 1;
+            const double iD = rcp(D);
+            const double ru = ru0 + mu * bur, gu = ru0 * ith;
+            const double rsel = role == 7 ? ru : role == 8 ? gu : 0.0;
+            const double coef = (bu * b[IB] - rsel) * iD;
+            ASC_UNROLL
+            for (int i = 0; i < 7; i++) a[i] = b[i] - mw[i] * coef;
+            outb[rowK + cj] = coef;
+            if (colr) {
+              double d0 = 0.0, d1 = 0.0;
+              ASC_UNROLL
+              for (int i = 0; i < 7; i++) { d0 -= a[i] * cc[i]; d1 += a[i] * rc1[i]; }
+              lds_d[grp][0][role] = d0;
+              lds_d[grp][1][role] = d1;
+            }
+            wsync();
+            if (rhs) {
+              double prc[7];
+              ASC_UNROLL
+              for (int i = 0; i < 7; i++) prc[i] = role == 9 ? 0.0 : lds_d[grp][role == 8 ? 1 : 0][i];
+              double uu = 0.0, vv = 0.0;
+              ASC_UNROLL
+              for (int i = 0; i < 7; i++) {
+                const double pj = a[i] - prc[i], sj = a[i] + pj;
+                uu += rc1[i] * sj; vv += cc[i] * sj;
+                a[i] = pj;
+              }
+              U += uu; V += vv;
+            }
+            const double k00 = bcast16<7>(coef), k01 = bcast16<8>(coef), k02 = bcast16<9>(coef);
+            const double Dk1 = D * k01, Dk2 = D * k02;
+            k10 += Dk1 * k00; k11 += Dk1 * k01; k12 += Dk1 * k02; k20 += Dk2 * k00; k22 += Dk2 * k02;
+          }
+        }
+        wsync();
+        PROF(2);
+        // ---- flush the feedback gains of the chunk (node-parallel) ---------------------------------------------------------
+        {
+          const int k = c * CH + role;
+          if (k < K && act && live) {
+            ASC_UNROLL
+            for (int i = 0; i < 10; i++) w[(size_t)(R_KA + i) * Kp + k] = outb[i * LDW + col];
+          }
+        }
+        wsync();
+        PROF(3);
+      }
+      // ---- border: the 2x2 Schur complement in (theta, nu3); inertia ---------------------------------------------------------
+      const double U0 = bcast16<7>(U), U1 = bcast16<8>(U), V1 = bcast16<8>(V), U2 = bcast16<9>(U), V2 = bcast16<9>(V);
+      if (act) {
+        const double S10 = k10 + 0.5 * (U0 - V1), S11 = k11 + U1, S12 = k12 + 0.5 * U2, S20 = k20 - 0.5 * V2, S22 = k22;
+        int ok = !bad;
+        double dth = 0.0, dnu3 = 0.0;
+        if (ok) {
+          const double itl = rcp(s.th - d.tlb), itu = rcp(d.tub - s.th);
+          const double rthp = sc[X_RTH] + mu * (itu - itl);
+          const double sth = s.zlt * itl + s.zut * itu + dw;
+          const double a11 = sth - S11, a12 = -S12, a22 = -S22;
+          const double b1 = -rthp + S10, b2 = -tm.e3 + S20;
+          const double det = a11 * a22 - a12 * a12;
+          if (det < 0.0) {
+            const double idet = 1.0 / det;
+            dth = (b1 * a22 - a12 * b2) * idet;
+            dnu3 = (a11 * b2 - a12 * b1) * idet;
+          } else {
+            ok = 0;
+          }
+        }
+        if (role == 0) {
+          if (ok) {
+            sc[X_DTH] = dth; sc[X_DNU3] = dnu3; sc[X_SIG1] = sig1; sc[X_SIG2] = sig2; sc[X_RS1] = rs1; sc[X_RS2] = rs2;
+            // the violations of the two terminal inequalities, g_i - s_i, are multiplied by sigma_i = z_i/s_i (1e14 for an active
+            // constraint at mu = 1e-10) wherever the eliminated slacks re-enter: every phase of this iteration must use the SAME
+            // bits -- a re-evaluation whose fused multiply-adds the compiler contracts differently differs by 1e-19, i.e. by
+            // 1e-5 in the multiplier step, and the Newton iteration then cycles at that level instead of converging
+            sc[X_CG1] = tm.g1 - s.s1; sc[X_CG2] = tm.g2 - s.s2;
+            sc[X_DWL] = dw; sc[X_STATE] = ST_FACTORED;
+          } else {
+            const double ndw = next_delta_w(dw, sc[X_DWL]);
+            if (ndw > 1e10) { sc[X_STATUS] = ASCENT_REGULARISATION_FAILED; sc[X_STATE] = ST_DONE; }
+            else sc[X_DW] = ndw;
+          }
+        }
+      }
+    }
+    wsync();
+    // ============================ F + A: forward and adjoint substitution ==========================================
+    state = (int)sc[X_STATE];
+    if (__any(state == ST_FACTORED)) {
+      const bool act = state == ST_FACTORED;
+      const Scal s = lds_scal(sc, X_S);
+      const double mu = sc[X_MU], dw = sc[X_DWL], dth = sc[X_DTH], dnu3 = sc[X_DNU3];
+      const double sig1 = sc[X_SIG1], sig2 = sc[X_SIG2], rs1 = sc[X_RS1], rs2 = sc[X_RS2];
+      const double *it = w + (size_t)((int)sc[X_CUR] * NIT) * Kp;
+      double *stp = w + (size_t)R_ST * Kp;
+      const double dt = hT * s.th, be = dt * d.alpha, cs = dt;
+      const double tau = fmax(0.99, 1.0 - mu);
+      // ---- forward -----------------------------------------------------------------------------------------------
+      {
+        const int rowA = (role < 8 ? S_G + role : role < 12 ? S_E + role - 8 : role < 15 ? S_K0 + role - 12 : S_G) * LDW;
+        const int rowB = (role < 7 ? S_C + role : role < 14 ? S_F + role - 7 : S_C) * LDW;
+        const int rowC = (role < 7 ? S_KA + role : S_KA) * LDW;
+        const int rowS = (role < 8 ? role : 0) * LDW;
+        const OneHot<8> hot(role);
+        double dzp[7];
+        ASC_UNROLL
+        for (int i = 0; i < 7; i++) dzp[i] = 0.0;
+        double rmax = 0.0, gsum = 0.0, adu = 1.0;
+        for (int c = 0; c < nch; c++) {
+          const int kn = c * CH + role;
+          double a_ = 0.5, m_ = 0.5, u_ = 0.0, zb[6] = {1, 1, 1, 1, 1, 1};
+          if (kn < K && act) {
+            double z[7], zp[7], F[7], G[8], E[4], ax, ay;
+            ASC_UNROLL
+            for (int i = 0; i < 7; i++) { z[i] = it[(O_Z + i) * Kp + kn]; zp[i] = kn > 0 ? it[(O_Z + i) * Kp + kn - 1] : 0.0; }
+            u_ = it[O_U * Kp + kn];
+            a_ = z[IA]; m_ = z[IM];
+            ASC_UNROLL
+            for (int b = 0; b < 6; b++) zb[b] = it[(O_ZB + b) * Kp + kn];
+            accel<1>(d, z[IX], z[IY], z[IA], z[IM], 0.0, 0.0, ax, ay, G, nullptr);
+            rhs_f(d, z, u_, ax, ay, F);
+            implicit_block(G, cs, E);
+            ASC_UNROLL
+            for (int i = 0; i < 8; i++) stage[(S_G + i) * LDW + col] = G[i];
+            ASC_UNROLL
+            for (int i = 0; i < 4; i++) stage[(S_E + i) * LDW + col] = E[i];
+            ASC_UNROLL
+            for (int i = 0; i < 7; i++) {
+              stage[(S_F + i) * LDW + col] = F[i];
+              stage[(S_C + i) * LDW + col] = z[i] - zp[i] - dt * F[i];
+            }
+            ASC_UNROLL
+            for (int i = 0; i < 10; i++) stage[(S_KA + i) * LDW + col] = w[(size_t)(R_KA + i) * Kp + kn];
+          }
+          wsync();
+          PROF(4);
+          if (act) {
+            for (int jj = 0; jj < CH; jj++) {
+              const int k = c * CH + jj;
+              if (k >= K) continue;
+              const int cj = grp * 16 + jj;
+              const double gA = stage[rowA + cj], gB = stage[rowB + cj], gC = stage[rowC + cj];
+              const double G[8] = {bcast16<0>(gA), bcast16<1>(gA), bcast16<2>(gA), bcast16<3>(gA),
+                                   bcast16<4>(gA), bcast16<5>(gA), bcast16<6>(gA), bcast16<7>(gA)};
+              const double E[4] = {bcast16<8>(gA), bcast16<9>(gA), bcast16<10>(gA), bcast16<11>(gA)};
+              const double k0[3] = {bcast16<12>(gA), bcast16<13>(gA), bcast16<14>(gA)};
+              const double cc[7] = {bcast16<0>(gB), bcast16<1>(gB), bcast16<2>(gB), bcast16<3>(gB),
+                                    bcast16<4>(gB), bcast16<5>(gB), bcast16<6>(gB)};
+              const double F[7] = {bcast16<7>(gB), bcast16<8>(gB), bcast16<9>(gB), bcast16<10>(gB),
+                                   bcast16<11>(gB), bcast16<12>(gB), bcast16<13>(gB)};
+              const double ka[7] = {bcast16<0>(gC), bcast16<1>(gC), bcast16<2>(gC), bcast16<3>(gC),
+                                    bcast16<4>(gC), bcast16<5>(gC), bcast16<6>(gC)};
+              double xi[7], dz[8];
+              double du = k0[0] + k0[1] * dth + k0[2] * dnu3;
+              ASC_UNROLL
+              for (int i = 0; i < 7; i++) {
+                xi[i] = dzp[i] - cc[i] + hT * F[i] * dth;
+                du -= ka[i] * xi[i];
+              }
+              xi[IW] += be * du;
+              solveA<0>(G, E, cs, xi, dz);
+              dz[7] = du;
+              outb[rowS + cj] = hot.pick(dz);
+              cpy<7>(dzp, dz);
+            }
+          }
+          wsync();
+          PROF(5);
+          // ---- node-parallel: store the primal step, bound-multiplier steps, fraction to the boundary ----------------------
+          if (kn < K && act) {
+            double dzn[8];
+            ASC_UNROLL
+            for (int i = 0; i < 8; i++) dzn[i] = outb[i * LDW + col];
+            const double id[6] = {rcp(a_), rcp(d.aub - a_), rcp(m_), rcp(1.0 - m_), rcp(u_ + 1.0), rcp(1.0 - u_)};
+            const double dza = dzn[IA], dzm = dzn[IM], du = dzn[7];
+            ASC_FTBR(rmax, id[0], dza); ASC_FTBR(rmax, id[1], -dza);
+            ASC_FTBR(rmax, id[2], dzm); ASC_FTBR(rmax, id[3], -dzm);
+            ASC_FTBR(rmax, id[4], du); ASC_FTBR(rmax, id[5], -du);
+            gsum += dza * (id[1] - id[0]) + dzm * (id[3] - id[2]) + du * (id[5] - id[4]);
+            const double dx3[3] = {dza, dzm, du};
+            double dzb[6];
+            ASC_UNROLL
+            for (int b = 0; b < 3; b++) {
+              const double zl = zb[2 * b], zu = zb[2 * b + 1];
+              dzb[2 * b] = id[2 * b] * (mu - zl * dx3[b]) - zl;
+              dzb[2 * b + 1] = id[2 * b + 1] * (mu + zu * dx3[b]) - zu;
+              ASC_FTB(adu, zl, dzb[2 * b]);
+              ASC_FTB(adu, zu, dzb[2 * b + 1]);
+            }
+            if (live) {
+              ASC_UNROLL
+              for (int i = 0; i < 7; i++) stp[(O_Z + i) * Kp + kn] = dzn[i];
+              stp[O_U * Kp + kn] = du;
+              ASC_UNROLL
+              for (int b = 0; b < 6; b++) stp[(O_ZB + b) * Kp + kn] = dzb[b];
+            }
+          }
+          wsync();
+          PROF(6);
+        }
+        rmax = gmax16(rmax); gsum = gsum16(gsum); adu = gmin16(adu);
+        // ---- adjoint (backwards over the chunks) ---------------------------------------------------------------------------
+        const int rowA2 = (role < 8 ? S_G + role : role < 12 ? S_E + role - 8 : S_G) * LDW;
+        const int rowB2 = (role < 7 ? S_R + role : role < 14 ? S_C + role - 7 : S_R) * LDW;
+        const int rowS2 = (role < 7 ? role : 0) * LDW;
+        const OneHot<7> hot7(role);
+        double dln[7];
+        ASC_UNROLL
+        for (int i = 0; i < 7; i++) dln[i] = 0.0;
+        double cl = 0.0, ccl = 0.0;
+        double dzK[7] = {0, 0, 0, 0, 0, 0, 0};
+#ifdef PERSIST_DEBUG
+        double dbg_r = 0.0, dbg_dl = 0.0;
+#endif
+        for (int c = nch - 1; c >= 0; c--) {
+          const int kn = c * CH + role;
+          double ccn[7] = {0, 0, 0, 0, 0, 0, 0};
+          if (kn < K && act) {
+            NodeIn n;
+            load_node(it, Kp, K, kn, n);
+            double dz[7];
+            ASC_UNROLL
+            for (int i = 0; i < 7; i++) dz[i] = stp[(O_Z + i) * Kp + kn];
+            double G[8], E[4], H[10], F[7], fl[7], ax, ay;
+            accel<2>(d, n.z[IX], n.z[IY], n.z[IA], n.z[IM], -cs * n.l[IVX], -cs * n.l[IVY], ax, ay, G, H);
+            rhs_f(d, n.z, n.u, ax, ay, F);
+            implicit_block(G, cs, E);
+            fzt_lambda(G, n.l, fl);
+            const double id0 = rcp(n.z[IA]), id1 = rcp(d.aub - n.z[IA]), id2 = rcp(n.z[IM]), id3 = rcp(1.0 - n.z[IM]);
+            H[7] += n.zb[0] * id0 + n.zb[1] * id1;
+            H[9] += n.zb[2] * id2 + n.zb[3] * id3;
+            double r[7];
+            ASC_UNROLL
+            for (int i = 0; i < 7; i++) {
+              const double rz = n.l[i] - cs * fl[i] - n.ln[i], gt = -hT * fl[i];
+              r[i] = -rz - gt * dth - dw * dz[i];
+              ccn[i] = n.z[i] - n.zp[i] - dt * F[i];
+              ccl += ccn[i] * n.l[i];
+            }
+            r[IA] -= mu * (id1 - id0);
+            r[IM] -= mu * (id3 - id2);
+            r[IX] -= H[0] * dz[IX] + H[1] * dz[IY] + H[2] * dz[IA] + H[3] * dz[IM];
+            r[IY] -= H[1] * dz[IX] + H[4] * dz[IY] + H[5] * dz[IA] + H[6] * dz[IM];
+            r[IA] -= H[2] * dz[IX] + H[5] * dz[IY] + H[7] * dz[IA] + H[8] * dz[IM];
+            r[IM] -= H[3] * dz[IX] + H[6] * dz[IY] + H[8] * dz[IA] + H[9] * dz[IM];
+            if (kn == K - 1) {
+              double QT[28], qd[7];
+              const Terminal tm = terminal_eval(d, n.z);
+              ASC_UNROLL
+              for (int i = 0; i < 28; i++) QT[i] = 0.0;
+              terminal_hessian(QT, tm, s.nu3, s.nu1, s.nu2, sig1, sig2);
+              symv(QT, dz, qd);
+              ASC_UNROLL
+              for (int i = 0; i < 7; i++) r[i] -= qd[i];
+              const double w1 = s.nu1 + sig1 * sc[X_CG1] + rs1, w2 = s.nu2 + sig2 * sc[X_CG2] + rs2;
+              r[IX] -= s.nu3 * tm.e3g[0] + w1 * tm.g1g[0] + tm.e3g[0] * dnu3;
+              r[IY] -= s.nu3 * tm.e3g[1] + w1 * tm.g1g[1] + tm.e3g[1] * dnu3;
+              r[IVX] -= s.nu3 * tm.e3g[2] + w2 * tm.g2g[0] + tm.e3g[2] * dnu3;
+              r[IVY] -= s.nu3 * tm.e3g[3] + w2 * tm.g2g[1] + tm.e3g[3] * dnu3;
+              cpy<7>(dzK, dz);
+            }
+            ASC_UNROLL
+            for (int i = 0; i < 8; i++) stage[(S_G + i) * LDW + col] = G[i];
+            ASC_UNROLL
+            for (int i = 0; i < 4; i++) stage[(S_E + i) * LDW + col] = E[i];
+            ASC_UNROLL
+            for (int i = 0; i < 7; i++) { stage[(S_R + i) * LDW + col] = r[i]; stage[(S_C + i) * LDW + col] = ccn[i]; }
+            (void)0;
+#ifdef PERSIST_DEBUG
+            for (int i = 0; i < 7; i++) dbg_r = fmax(dbg_r, fabs(r[i]));
+            if (blockIdx.x == 0 && grp == 0 && sc[X_ITERS] == 20.0)
+              for (int i = 0; i < 7; i++) if (fabs(r[i]) > 1e-6) printf("[persist]      adj node %d field %d r %.4e  l %.6e fl %.6e ln %.6e cs %.4e rzraw %.4e mu-term %.4e dz %.3e zb0 %.3e zb1 %.3e zb2 %.3e zb3 %.3e\n", kn, i, r[i], n.l[i], fl[i], n.ln[i], cs, n.l[i] - cs * fl[i] - n.ln[i], i == IA ? mu * (id1 - id0) : i == IM ? mu * (id3 - id2) : 0.0, dz[i], n.zb[0], n.zb[1], n.zb[2], n.zb[3]);
+#endif
+          }
+          wsync();
+          PROF(7);
+          if (act) {
+            for (int jj = CH - 1; jj >= 0; jj--) {
+              const int k = c * CH + jj;
+              if (k >= K) continue;
+              const int cj = grp * 16 + jj;
+              const double gA = stage[rowA2 + cj], gB = stage[rowB2 + cj];
+              const double G[8] = {bcast16<0>(gA), bcast16<1>(gA), bcast16<2>(gA), bcast16<3>(gA),
+                                   bcast16<4>(gA), bcast16<5>(gA), bcast16<6>(gA), bcast16<7>(gA)};
+              const double E[4] = {bcast16<8>(gA), bcast16<9>(gA), bcast16<10>(gA), bcast16<11>(gA)};
+              const double rr[7] = {bcast16<0>(gB), bcast16<1>(gB), bcast16<2>(gB), bcast16<3>(gB),
+                                    bcast16<4>(gB), bcast16<5>(gB), bcast16<6>(gB)};
+              const double cc[7] = {bcast16<7>(gB), bcast16<8>(gB), bcast16<9>(gB), bcast16<10>(gB),
+                                    bcast16<11>(gB), bcast16<12>(gB), bcast16<13>(gB)};
+              double r[7], dl[7];
+              ASC_UNROLL
+              for (int i = 0; i < 7; i++) r[i] = rr[i] + dln[i];
+              solveAT<0>(G, E, cs, r, dl);
+              outb[rowS2 + cj] = hot7.pick(dl);
+#ifdef PERSIST_DEBUG
+              for (int i = 0; i < 7; i++) dbg_dl = fmax(dbg_dl, fabs(dl[i]));
+#endif
+              ASC_UNROLL
+              for (int i = 0; i < 7; i++) cl += cc[i] * dl[i];
+              cpy<7>(dln, dl);
+            }
+          }
+          wsync();
+          if (kn < K && act && live) {
+            ASC_UNROLL
+            for (int i = 0; i < 7; i++) stp[(O_L + i) * Kp + kn] = outb[i * LDW + col];
+          }
+          wsync();
+          PROF(8);
+        }
+#ifdef PERSIST_DEBUG
+        dbg_r = gmax16(dbg_r);
+        if (blockIdx.x == 0 && lane == 0) printf("[persist]    newton: dth %.3e dnu3 %.3e max|r_adj| %.3e max|dlam| %.3e rmax %.3e mu %.1e dw %.1e act %d\n", dth, dnu3, dbg_r, dbg_dl, rmax, mu, dw, (int)act);
+#endif
+        // ---- scalars of the step, merit bookkeeping -------------------------------------------------------------------------
+        ccl = gsum16(ccl);
+        ASC_UNROLL
+        for (int i = 0; i < 7; i++) dzK[i] = gsum16(dzK[i]);          // only the lane of the last node holds non-zeros
+        if (act) {
+          cl += ccl;
+          double zK[7];
+          ASC_UNROLL
+          for (int i = 0; i < 7; i++) zK[i] = it[(O_Z + i) * Kp + K - 1];
+          const Terminal tm = terminal_eval(d, zK);
+          Scal ds;
+          ds.th = dth; ds.nu3 = dnu3;
+          ds.s1 = sc[X_CG1] + tm.g1g[0] * dzK[IX] + tm.g1g[1] * dzK[IY];
+          ds.s2 = sc[X_CG2] + tm.g2g[0] * dzK[IVX] + tm.g2g[1] * dzK[IVY];
+          ds.nu1 = sig1 * ds.s1 + rs1;
+          ds.nu2 = sig2 * ds.s2 + rs2;
+          ds.zs1 = mu / s.s1 - s.zs1 - s.zs1 / s.s1 * ds.s1;
+          ds.zs2 = mu / s.s2 - s.zs2 - s.zs2 / s.s2 * ds.s2;
+          const double dl_ = s.th - d.tlb, dU = d.tub - s.th;
+          ds.zlt = mu / dl_ - s.zlt - s.zlt / dl_ * ds.th;
+          ds.zut = mu / dU - s.zut + s.zut / dU * ds.th;
+          double apr = 1.0;
+          if (rmax * apr > tau) apr = tau / rmax;
+          ASC_FTB(apr, dl_, ds.th); ASC_FTB(apr, dU, -ds.th);
+          ASC_FTB(apr, s.s1, ds.s1); ASC_FTB(apr, s.s2, ds.s2);
+          ASC_FTB(adu, s.zlt, ds.zlt); ASC_FTB(adu, s.zut, ds.zut);
+          ASC_FTB(adu, s.zs1, ds.zs1); ASC_FTB(adu, s.zs2, ds.zs2);
+          double gd = mu * gsum;
+          gd += ds.th * (1.0 - mu / dl_ + mu / dU) - mu * ds.s1 / s.s1 - mu * ds.s2 / s.s2;
+          cl += tm.e3 * (s.nu3 + ds.nu3) + sc[X_CG1] * (s.nu1 + ds.nu1) + sc[X_CG2] * (s.nu2 + ds.nu2);
+          const double c1 = sc[X_C1], slog = sc[X_SL];
+          double nu_pen = sc[X_NUP];
+          const double curv = -gd + cl;
+          if (c1 > 0.0) {
+            const double need = (gd + 0.5 * fmax(curv, 0.0)) / (0.9 * c1);
+            if (nu_pen < need) nu_pen = need + 1.0;
+          }
+          wsync();
+          if (role == 0) {
+            put_scal(sc, X_D, ds);
+            sc[X_NUP] = nu_pen;
+            sc[X_DM] = gd - nu_pen * c1;
+            sc[X_PHI0] = s.th - mu * slog + nu_pen * c1;
+            sc[X_ALPHA] = apr; sc[X_ADU] = adu; sc[X_LS] = 0.0;
+            sc[X_STATE] = ST_TRIAL;
+          }
+        }
+      }
+    }
+    wsync();
+  }
+  wsync();
+  PROF_END;
+  if (live)
+    for (int r = role; r < NSCAL; r += 16) gsc[r] = sc[r];
+}
+
+}  // namespace
+
+namespace ascent {
+
+static PGeo geo_of(int K) {
+  PGeo g;
+  g.K = K; g.nch = (K + CH - 1) / CH; g.Kp = g.nch * CH;
+  return g;
+}
+
+size_t persist_ws_bytes(int K, long batch) { return (size_t)batch * geo_of(K).nlp_doubles() * sizeof(double) + 64; }
+
+#define PCHK2(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf(err, errlen, "%s: %s", #call, hipGetErrorString(e_)); return ASCENT_E_HIP; } } while (0)
+
+int persist_run(const ascent_params *dp, long batch, int K, double *ws, const double *dguess, int warm, int max_iter, double tol,
+                double mu0, double *dtraj, double *dtf, int *dstatus, int *diters, double *dblob, hipStream_t stream, char *err,
+                size_t errlen) {
+  const PGeo g = geo_of(K);
+  const dim3 ng((unsigned)((g.Kp + WAVE - 1) / WAVE), (unsigned)batch);
+  hipLaunchKernelGGL(p_init, ng, dim3(WAVE), 0, stream, dp, batch, g, ws, dguess, warm, mu0);
+  hipLaunchKernelGGL(p_solve, dim3((unsigned)((batch + NPW - 1) / NPW)), dim3(WAVE), 0, stream, dp, batch, g, ws, max_iter, tol);
+  hipLaunchKernelGGL(p_finish, ng, dim3(WAVE), 0, stream, dp, batch, g, (const double *)ws, dtraj, dtf, dstatus, diters, dblob);
+  PCHK2(hipGetLastError());
+  return ASCENT_OK;
+}
+
+}  // namespace ascent

@@ -1,0 +1,17 @@
+// Host interface of the persistent solver kernel (ascent_persist.hip), used by the C ABI in ascent_solver.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstddef>
+#include "ascent.h"
+
+namespace ascent {
+
+size_t persist_ws_bytes(int K, long batch);
+
+// One grid level, backward Euler, current formulation: three launches (initial point, the whole interior-point loop, results),
+// all asynchronous on `stream`; device pointers; blob / traj layouts of include/ascent.h.
+int persist_run(const ascent_params *dp, long batch, int K, double *ws, const double *dguess, int warm, int max_iter, double tol,
+                double mu0, double *dtraj, double *dtf, int *dstatus, int *diters, double *dblob, hipStream_t stream, char *err,
+                size_t errlen);
+
+}  // namespace ascent

@@ -34,6 +34,7 @@
 #include "ascent_pipeline.hpp"
 #include "ascent_dense.hpp"
 #include "ascent_blocktri.hpp"
+#include "ascent_persist.hpp"
 
 using namespace ascent;
 
@@ -932,6 +933,18 @@ bool use_pcr_newton(int64_t batch) {
   return batch <= 64;      // scripts/small_batch_paths.py: 13.1 vs 15.8 ms at 64 NLPs (N=200), 248 vs 284 ms (N=2000)
 }
 
+// The persistent kernel (ascent_persist.hip: one wavefront owns four NLPs for the whole solve, node blocks handed from the
+// node-parallel phases to the serial sweeps through LDS) -- backward Euler, current formulation.
+bool use_persist_path(const ascent_opts *o, int64_t batch) {
+  if (o->scheme != 0 || o->formulation != 0) return false;
+  const char *e = getenv("ASCENT_PIPELINE");
+  if (e) return !strcmp(e, "persist");
+  if (getenv("ASCENT_FACTOR")) return false;          // an explicit choice between the split pipeline's sweep kernels
+  // measured (scripts/batch_sweep2.py, N=200): 576k NLPs/s at 4096 against 374k for the split pipeline; ahead of every
+  // other path from 9 NLPs up to 24 576 (596k vs 538k fused); the fused kernel takes over at 32 768 (674k vs 603k)
+  return batch < 28672;
+}
+
 struct DeviceWs {
   double *ws = nullptr;
   size_t bytes = 0;
@@ -1090,8 +1103,9 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
   // the trapezoid scheme and the v1 formulation exist in the split pipeline only
   const bool dense = use_dense_path(o, batch);
   const bool pcr = dense && use_pcr_newton(batch);
+  const bool persist = !dense && use_persist_path(o, batch);
   const bool split = o->scheme == 1 || o->formulation == 1 || use_split_pipeline(batch);
-  rc = ensure_ws(device_id, dense ? (pcr ? dense_pcr_ws_bytes(K, (long)batch) : dense_ws_bytes(K, (long)batch)) : split ? pipeline_ws_bytes(K, (long)batch) : ws_bytes(K, batch, lpt));
+  rc = ensure_ws(device_id, persist ? persist_ws_bytes(K, (long)batch) : dense ? (pcr ? dense_pcr_ws_bytes(K, (long)batch) : dense_ws_bytes(K, (long)batch)) : split ? pipeline_ws_bytes(K, (long)batch) : ws_bytes(K, batch, lpt));
   if (rc) return rc;
   DeviceWs &w = g_ws[device_id];
   const double mu0 = o->mu_init > 0 ? o->mu_init : (o->warm_start ? 1e-4 : 0.1);
@@ -1166,6 +1180,10 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
     if (dense) {
       rc = dense_run(dp, (long)batch, Kl, (int)o->scheme, 0, w.ws, g_l, warm_l, (int)o->max_iter, tol_l, mu_l, traj_l, tf_l, st_l,
                      it_l, blob_l, stream, g_err, sizeof g_err, pcr ? 1 : 0);
+      if (rc) return rc;
+    } else if (persist) {
+      rc = persist_run(dp, (long)batch, Kl, w.ws, g_l, warm_l, (int)o->max_iter, tol_l, mu_l, traj_l, tf_l, st_l, it_l, blob_l, stream,
+                       g_err, sizeof g_err);
       if (rc) return rc;
     } else if (split) {
       rc = pipeline_run(dp, (long)batch, Kl, (int)o->scheme, (int)o->formulation, w.ws, g_l, warm_l, (int)o->max_iter, tol_l, mu_l,

@@ -9,6 +9,8 @@ import csv, glob, json, os, re, sys
 fetch_dir, write_dir, stats_dir, n_solves = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
 key = sys.argv[5] if len(sys.argv) > 5 else "batch4096"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from bench import source_sha16  # noqa: E402  (the stamp bench.py checks before it quotes this file)
 
 
 def short(name):
@@ -42,6 +44,7 @@ for r in csv.DictReader(open(f)):
     stats[k] = {"calls_per_solve": int(r["Calls"]) / n_solves, "avg_us": float(r["AverageNs"]) / 1e3,
                 "ms_per_solve": float(r["TotalDurationNs"]) / 1e6 / n_solves, "percent": float(r["Percentage"])}
 out = {
+    "source_sha16": source_sha16(),
     "workload": "BASELINE.json configs[2], split pipeline with 16-lane sweeps, cold start, tol 1e-9",
     "hbm_bytes_per_launch": (rd + wr) / n_solves, "read_bytes": rd / n_solves, "write_bytes": wr / n_solves,
     "definition": "one launch = one bench step = one whole solve of the batch (all kernels of all rounds)",

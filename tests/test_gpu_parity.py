@@ -182,6 +182,47 @@ def test_split_and_fused_paths_agree(coracle, monkeypatch):
         assert np.all(m.status == 1) and np.all(m.iters == 8)
 
 
+def test_persistent_kernel_matches_split_pipeline_and_oracle(coracle, monkeypatch):
+    """The persistent kernel (csrc/ascent_persist.hip: one wavefront owns four NLPs for the whole solve, node blocks handed
+    to the 16-lane sweeps through LDS; the default for 9 .. 28 671 NLPs of scheme 0) against the split pipeline and the
+    oracle: same algorithm, same arithmetic per lane -- identical iteration counts on every problem, t_f to rounding.
+    Ragged batches exercise partially filled wavefronts (dead groups) and chunks (199 = 12 x 16 + 7 nodes)."""
+    for B, nt in ((5, 200), (67, 200), (130, 37), (1000, 200), (9, 1000)):
+        S = A.sweep_isp_drymass()[:: max(1, 4096 // B)][:B]
+        out = {}
+        for mode in ("persist", "split"):
+            monkeypatch.setenv("ASCENT_PIPELINE", mode)
+            out[mode] = A.solve_batch(S, nt, tol=1e-9, want_blob=True, max_iter=500)
+            assert np.all(out[mode].status == 0)
+        if nt >= 200:
+            assert np.array_equal(out["persist"].iters, out["split"].iters)
+        else:     # (37 nodes: no nested iteration, 17-22 iterations from the cold start; the convergence test is a rounding knife edge)
+            assert np.abs(out["persist"].iters.astype(int) - out["split"].iters).max() <= 1
+        assert np.abs(out["persist"].tf - out["split"].tf).max() <= 1e-9
+        for f in (0, 1, 2, 3, 6, 9):
+            assert np.abs(out["persist"].traj[f] - out["split"].traj[f]).max() <= 1e-6 * max(1.0, np.abs(out["split"].traj[f]).max())
+        idx = np.linspace(0, B - 1, min(B, 24)).astype(int)
+        ref = coracle.solve_batch(S[idx], nt, 500, 1e-9)
+        assert np.abs(out["persist"].iters[idx].astype(int) - ref["iters"]).max() <= (0 if nt >= 200 else 1)
+        assert np.abs(out["persist"].tf[idx] - ref["tf"]).max() <= 1e-9
+    monkeypatch.setenv("ASCENT_PIPELINE", "persist")
+    # warm start, iteration cap, a problem that cannot converge, the default dispatch
+    S = A.sweep_isp_drymass(6, 5)
+    w = A.solve_batch(S, NT, tol=1e-9, guess=out["persist"].blob[:, :1].repeat(30, 1) if False else A.solve_batch(S, NT, tol=1e-9, want_blob=True).blob,
+                      warm_start=2, mu_init=1e-9)
+    assert np.all(w.status == 0) and w.iters.max() <= 8
+    m = A.solve_batch(S[:5], NT, tol=1e-9, max_iter=4, coarse_nodes=-1)
+    assert np.all(m.status == 1) and np.all(m.iters == 4)
+    bad = A.solve_batch(A.AscentParams(Ft=3000.0).as_row()[None].repeat(9, 0), NT, tol=1e-9, max_iter=60)
+    assert np.all(bad.status != 0)
+    monkeypatch.delenv("ASCENT_PIPELINE")
+    S = A.sweep_isp_drymass()
+    d = A.solve_batch(S, NT, tol=1e-9, want_traj=False)                     # default dispatch at 4096 = the persistent kernel
+    monkeypatch.setenv("ASCENT_PIPELINE", "split")
+    s = A.solve_batch(S, NT, tol=1e-9, want_traj=False)
+    assert np.all(d.status == 0) and np.array_equal(d.iters, s.iters) and np.abs(d.tf - s.tf).max() <= 1e-12
+
+
 def test_wide_and_one_lane_sweeps_agree(coracle, monkeypatch):
     """The split pipeline has two implementations of its three serial sweeps: one lane per NLP, and 16 lanes per
     NLP (DPP row broadcasts + LDS transpose; used for batches <= 4096; ASCENT_FACTOR=lane|wide overrides).  Same
