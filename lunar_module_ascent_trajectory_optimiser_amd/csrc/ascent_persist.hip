@@ -43,6 +43,9 @@ constexpr int OUT_ROWS = 11;
 enum {
   X_STATE, X_ITERS, X_STATUS, X_CUR, X_FIRST, X_LS, X_MU, X_NUP, X_DW, X_DWL, X_ALPHA, X_ADU, X_PHI0, X_DM, X_C1, X_SL,
   X_RTH, X_DTH, X_DNU3, X_SIG1, X_SIG2, X_RS1, X_RS2, X_CG1, X_CG2,
+  X_TEVAL,                   // the trial point of the next round has been evaluated already (by the adjoint phase)
+  X_P,                       // 9 reduced partials of that trial point: rd cinf pmin pmax l1 zsum rth c1 sl
+  X_PEND = X_P + 8,
   X_S,                       // 10 scalars of the iterate
   X_T = X_S + 10,            // 10 trial scalars
   X_D = X_T + 10,            // 10 step scalars
@@ -246,6 +249,84 @@ ASC_DEV void load_node(const double *it, int Kp, int K, int k, NodeIn &n) {
   for (int b = 0; b < 6; b++) n.zb[b] = it[(O_ZB + b) * Kp + k];
 }
 
+// Partial sums of the merit function and the KKT error over the nodes a lane evaluates
+struct Part {
+  double rd, cinf, pmin, pmax, l1, zsum, rth, c1, sl;
+  ASC_DEV void clear() { rd = 0.0; cinf = 0.0; pmin = 1e300; pmax = -1e300; l1 = 0.0; zsum = 0.0; rth = 0.0; c1 = 0.0; sl = 0.0; }
+  ASC_DEV void reduce16() {
+    rd = gmax16(rd); cinf = gmax16(cinf); pmin = gmin16(pmin); pmax = gmax16(pmax);
+    l1 = gsum16(l1); zsum = gsum16(zsum); rth = gsum16(rth); c1 = gsum16(c1); sl = gsum16(sl);
+  }
+};
+struct TrialCtx {       // what the trial point of an NLP needs besides the node data
+  double alpha, adu, mlo, mhi, dt, be, hT;
+  bool first;
+  Scal stt;
+};
+
+// The trial point x + alpha dx at node k (iterate n, step dn), stored into the other iterate buffer, and its pieces of the
+// l1 merit function and of the KKT error (Launch_Optimiser.py:114-136 evaluated once, with first derivatives).
+ASC_DEV void trial_node(const Der &d, int K, int Kp, int k, const NodeIn &n, const NodeIn &dn, const TrialCtx &t, bool live,
+                        double *in, Part &P) {
+  const double alpha = t.alpha;
+  double z[7], zp[7], l[7], ln[7], zb[6];
+  ASC_UNROLL
+  for (int i = 0; i < 7; i++) {
+    z[i] = n.z[i] + alpha * dn.z[i]; zp[i] = n.zp[i] + alpha * dn.zp[i];
+    l[i] = n.l[i] + alpha * dn.l[i]; ln[i] = n.ln[i] + alpha * dn.ln[i];
+  }
+  const double u = n.u + alpha * dn.u;
+  const double dist[6] = {z[IA], d.aub - z[IA], z[IM], 1.0 - z[IM], u + 1.0, 1.0 - u};
+  ASC_UNROLL
+  for (int b = 0; b < 6; b++) {
+    const double id = rcp(dist[b]);
+    zb[b] = t.first ? n.zb[b] : fmin(fmax(n.zb[b] + t.adu * dn.zb[b], t.mlo * id), t.mhi * id);
+  }
+  if (live) {
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) { in[(O_Z + i) * Kp + k] = z[i]; in[(O_L + i) * Kp + k] = l[i]; }
+    in[O_U * Kp + k] = u;
+    ASC_UNROLL
+    for (int b = 0; b < 6; b++) in[(O_ZB + b) * Kp + k] = zb[b];
+  }
+  double G[8], F[7], fl[7], ax, ay;
+  accel<1>(d, z[IX], z[IY], z[IA], z[IM], 0.0, 0.0, ax, ay, G, nullptr);
+  rhs_f(d, z, u, ax, ay, F);
+  fzt_lambda(G, l, fl);
+  double r[7];
+  ASC_UNROLL
+  for (int i = 0; i < 7; i++) {
+    r[i] = l[i] - t.dt * fl[i] - ln[i];
+    const double cc = z[i] - zp[i] - t.dt * F[i];
+    P.c1 += fabs(cc);
+    P.cinf = fmax(P.cinf, fabs(cc));
+    P.rth -= t.hT * F[i] * l[i];
+    P.l1 += fabs(l[i]);
+  }
+  r[IA] += zb[1] - zb[0];
+  r[IM] += zb[3] - zb[2];
+  if (k == K - 1) {
+    const Scal &stt = t.stt;
+    const Terminal tt = terminal_eval(d, z);
+    r[IX] += stt.nu3 * tt.e3g[0] + stt.nu1 * tt.g1g[0];
+    r[IY] += stt.nu3 * tt.e3g[1] + stt.nu1 * tt.g1g[1];
+    r[IVX] += stt.nu3 * tt.e3g[2] + stt.nu2 * tt.g2g[0];
+    r[IVY] += stt.nu3 * tt.e3g[3] + stt.nu2 * tt.g2g[1];
+    const double e1 = fabs(tt.e3), e2 = fabs(tt.g1 - stt.s1), e3 = fabs(tt.g2 - stt.s2);
+    P.cinf = fmax(P.cinf, fmax(e1, fmax(e2, e3)));
+    P.c1 += e1 + e2 + e3;
+    const double ps = ((stt.th - d.tlb) * (d.tub - stt.th)) * (stt.s1 * stt.s2);
+    P.sl += ps > 0.0 ? log(ps) : NAN;
+  }
+  ASC_UNROLL
+  for (int i = 0; i < 7; i++) P.rd = fmax(P.rd, fabs(r[i]));
+  P.rd = fmax(P.rd, fabs(-t.be * l[IW] - zb[4] + zb[5]));
+  ASC_UNROLL
+  for (int b = 0; b < 6; b++) { const double pr = dist[b] * zb[b]; P.pmin = fmin(P.pmin, pr); P.pmax = fmax(P.pmax, pr); P.zsum += zb[b]; }
+  const double pa = dist[0] * dist[1], pm = dist[2] * dist[3], pu = dist[4] * dist[5];
+  P.sl += (pa > 0.0 && pm > 0.0 && pu > 0.0) ? log(pa * pm * pu) : NAN;
+}
+
 #ifdef PERSIST_PROFILE      // diagnostic build (scripts/persist_profile.py): shader cycles per phase, wavefront 0
 #define PROF_DECL long long prof_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long pt_ = clock64();
 #define PROF(i_) do { const long long t1_ = clock64(); prof_[i_] += t1_ - pt_; pt_ = t1_; } while (0)
@@ -262,6 +343,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
   __shared__ double lds_t[NPW][7][7];
   __shared__ double lds_d[NPW][2][8];
   __shared__ double lsc[NPW][NSCAL];
+  __shared__ double lds_c[NPW][8];                      // adjoint phase: the multiplier step of the first node of the chunk above
   const int lane = threadIdx.x, grp = lane >> 4, role = lane & 15;
   const long p = (long)blockIdx.x * NPW + grp;
   const bool live = p < batch;
@@ -295,88 +377,27 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
       double *in = w + (size_t)((1 - cur) * NIT) * Kp;
       const double dt = hT * stt.th, be = dt * d.alpha;
       const double mlo = mu * 1e-10, mhi = mu * 1e10;
-      double rd = 0.0, cinf = 0.0, pmin = 1e300, pmax = -1e300, l1 = 0.0, zsum = 0.0, rth = 0.0, c1 = 0.0, sl = 0.0;
-#ifdef PERSIST_DEBUG
-      double dbg_stepl = 0.0;
-#endif
-      for (int c = 0; c < nch; c++) {
-        const int k = c * CH + role;
-        if (k < K) {
-          NodeIn n, dn;
-          load_node(ic, Kp, K, k, n);
-          load_node(stp, Kp, K, k, dn);
-#ifdef PERSIST_DEBUG
-          for (int i = 0; i < 7; i++) dbg_stepl = fmax(dbg_stepl, fabs(dn.l[i]));
-#endif
-          double z[7], zp[7], l[7], ln[7], zb[6];
-          ASC_UNROLL
-          for (int i = 0; i < 7; i++) {
-            z[i] = n.z[i] + alpha * dn.z[i]; zp[i] = n.zp[i] + alpha * dn.zp[i];
-            l[i] = n.l[i] + alpha * dn.l[i]; ln[i] = n.ln[i] + alpha * dn.ln[i];
+      Part P;
+      if (sc[X_TEVAL] != 0.0) {             // evaluated by the adjoint phase of the previous round
+        P.rd = sc[X_P + 0]; P.cinf = sc[X_P + 1]; P.pmin = sc[X_P + 2]; P.pmax = sc[X_P + 3]; P.l1 = sc[X_P + 4];
+        P.zsum = sc[X_P + 5]; P.rth = sc[X_P + 6]; P.c1 = sc[X_P + 7]; P.sl = sc[X_P + 8];
+      } else {
+        TrialCtx t;
+        t.alpha = alpha; t.adu = adu; t.mlo = mlo; t.mhi = mhi; t.dt = dt; t.be = be; t.hT = hT; t.first = first; t.stt = stt;
+        P.clear();
+        for (int c = 0; c < nch; c++) {
+          const int k = c * CH + role;
+          if (k < K) {
+            NodeIn n, dn;
+            load_node(ic, Kp, K, k, n);
+            load_node(stp, Kp, K, k, dn);
+            trial_node(d, K, Kp, k, n, dn, t, live, in, P);
           }
-          const double u = n.u + alpha * dn.u;
-          const double dist[6] = {z[IA], d.aub - z[IA], z[IM], 1.0 - z[IM], u + 1.0, 1.0 - u};
-          ASC_UNROLL
-          for (int b = 0; b < 6; b++) {
-            const double id = rcp(dist[b]);
-            zb[b] = first ? n.zb[b] : fmin(fmax(n.zb[b] + adu * dn.zb[b], mlo * id), mhi * id);
-          }
-          if (live) {
-            ASC_UNROLL
-            for (int i = 0; i < 7; i++) { in[(O_Z + i) * Kp + k] = z[i]; in[(O_L + i) * Kp + k] = l[i]; }
-            in[O_U * Kp + k] = u;
-            ASC_UNROLL
-            for (int b = 0; b < 6; b++) in[(O_ZB + b) * Kp + k] = zb[b];
-          }
-          double G[8], F[7], fl[7], ax, ay;
-          accel<1>(d, z[IX], z[IY], z[IA], z[IM], 0.0, 0.0, ax, ay, G, nullptr);
-          rhs_f(d, z, u, ax, ay, F);
-          fzt_lambda(G, l, fl);
-          double r[7];
-          ASC_UNROLL
-          for (int i = 0; i < 7; i++) {
-            r[i] = l[i] - dt * fl[i] - ln[i];
-            const double cc = z[i] - zp[i] - dt * F[i];
-            c1 += fabs(cc);
-            cinf = fmax(cinf, fabs(cc));
-            rth -= hT * F[i] * l[i];
-            l1 += fabs(l[i]);
-          }
-          r[IA] += zb[1] - zb[0];
-          r[IM] += zb[3] - zb[2];
-          if (k == K - 1) {
-            const Terminal t = terminal_eval(d, z);
-            r[IX] += stt.nu3 * t.e3g[0] + stt.nu1 * t.g1g[0];
-            r[IY] += stt.nu3 * t.e3g[1] + stt.nu1 * t.g1g[1];
-            r[IVX] += stt.nu3 * t.e3g[2] + stt.nu2 * t.g2g[0];
-            r[IVY] += stt.nu3 * t.e3g[3] + stt.nu2 * t.g2g[1];
-            const double e1 = fabs(t.e3), e2 = fabs(t.g1 - stt.s1), e3 = fabs(t.g2 - stt.s2);
-            cinf = fmax(cinf, fmax(e1, fmax(e2, e3)));
-            c1 += e1 + e2 + e3;
-            const double ps = ((stt.th - d.tlb) * (d.tub - stt.th)) * (stt.s1 * stt.s2);
-            sl += ps > 0.0 ? log(ps) : NAN;
-          }
-#ifdef PERSIST_DEBUG
-          if (blockIdx.x == 0 && grp == 0 && sc[X_ITERS] == 20.0) {
-            for (int i = 0; i < 7; i++) if (fabs(r[i]) > 1e-6) printf("[persist]      trial node %d field %d r %.4e l %.6e fl %.6e ln %.6e dt %.4e zb %.3e %.3e %.3e %.3e\n", k, i, r[i], l[i], fl[i], ln[i], dt, zb[0], zb[1], zb[2], zb[3]);
-            if (fabs(-be * l[IB] - zb[4] + zb[5]) > 1e-6) printf("[persist]      trial node %d control row %.4e\n", k, -be * l[IB] - zb[4] + zb[5]);
-          }
-#endif
-          ASC_UNROLL
-          for (int i = 0; i < 7; i++) rd = fmax(rd, fabs(r[i]));
-          rd = fmax(rd, fabs(-be * l[IB] - zb[4] + zb[5]));
-          ASC_UNROLL
-          for (int b = 0; b < 6; b++) { const double pr = dist[b] * zb[b]; pmin = fmin(pmin, pr); pmax = fmax(pmax, pr); zsum += zb[b]; }
-          const double pa = dist[0] * dist[1], pm = dist[2] * dist[3], pu = dist[4] * dist[5];
-          sl += (pa > 0.0 && pm > 0.0 && pu > 0.0) ? log(pa * pm * pu) : NAN;
         }
+        P.reduce16();
       }
-#ifdef PERSIST_DEBUG
-      dbg_stepl = gmax16(dbg_stepl);
-      if (blockIdx.x == 0 && lane == 0) printf("[persist]    trial: alpha %.3g cur %d max|dlam read| %.3e first %d\n", alpha, cur, dbg_stepl, (int)first);
-#endif
-      rd = gmax16(rd); cinf = gmax16(cinf); pmin = gmin16(pmin); pmax = gmax16(pmax);
-      l1 = gsum16(l1); zsum = gsum16(zsum); rth = 1.0 + gsum16(rth); c1 = gsum16(c1); sl = gsum16(sl);
+      double rd = P.rd, cinf = P.cinf, pmin = P.pmin, pmax = P.pmax, l1 = P.l1, zsum = P.zsum;
+      const double rth = 1.0 + P.rth, c1 = P.c1, sl = P.sl;
       // ---- decisions (all 16 lanes of the NLP alike; lane 0 writes) -------------------------------------------------
       double nu_pen = sc[X_NUP], iters = sc[X_ITERS], mu2 = mu;
       int nstate = ST_FACTOR;
@@ -384,15 +405,12 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
       if (!first) {
         const double phi0 = sc[X_PHI0], Dm = sc[X_DM];
         const double phit = stt.th - mu * sl + nu_pen * c1;
-#ifdef PERSIST_DEBUG
-        if (blockIdx.x == 0 && lane == 0) printf("[persist] it %d alpha %.4g adu %.4g mu %.2e phit %.17g phi0 %.17g Dm %.3e c1 %.3e sl %.12g nu %.3g ls %d\n", (int)iters, alpha, adu, mu, phit, phi0, Dm, c1, sl, nu_pen, (int)sc[X_LS]);
-#endif
         if (!(isfinite(phit) && phit <= phi0 + 1e-8 * alpha * Dm + 2.220446049250313e-15 * fabs(phi0))) {
           accepted = false;
           const int ls = (int)sc[X_LS] + 1;
           wsync();
           if (role == 0) {
-            sc[X_LS] = ls;
+            sc[X_LS] = ls; sc[X_TEVAL] = 0.0;
             if (ls >= 40) { sc[X_STATUS] = ASCENT_LINESEARCH_FAILED; sc[X_STATE] = ST_DONE; }
             else sc[X_ALPHA] = 0.5 * alpha;
           }
@@ -413,10 +431,6 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
         zsum += stt.zlt + stt.zut + stt.zs1 + stt.zs2;
         e.sd = fmax(100.0, (l1 + zsum) / (double)(13 * K + 7)) * 0.01;
         int status = -1;
-#ifdef PERSIST_DEBUG
-        if (blockIdx.x == 0 && lane == 0) printf("[persist]    node rd %.3e | th %.3e | s1 %.3e s2 %.3e | dw_last %.2e state dw %.2e\n", rd, fabs(rth - stt.zlt + stt.zut), fabs(-stt.nu1 - stt.zs1), fabs(-stt.nu2 - stt.zs2), sc[X_DWL], sc[X_DW]);
-        if (blockIdx.x == 0 && lane == 0) printf("[persist]    accepted it %d: E0 %.3e (rd %.3e cinf %.3e pmin %.3e pmax %.3e sd %.3e) rth-res %.3e mu %.1e\n", (int)iters, e.err(0.0), e.rd, e.cinf, e.pmin, e.pmax, e.sd, fabs(rth - stt.zlt + stt.zut), mu);
-#endif
         if (e.err(0.0) <= tol) { status = ASCENT_CONVERGED; nstate = ST_DONE; }
         else if ((int)iters >= max_iter) { status = ASCENT_MAX_ITER; nstate = ST_DONE; }
         else {
@@ -429,7 +443,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
         if (role == 0) {
           put_scal(sc, X_S, stt);
           sc[X_CUR] = 1 - cur; sc[X_FIRST] = 0.0; sc[X_ITERS] = iters; sc[X_LS] = 0.0; sc[X_C1] = c1; sc[X_SL] = sl; sc[X_RTH] = rth;
-          sc[X_MU] = mu2; sc[X_NUP] = nu_pen; sc[X_DW] = 0.0; sc[X_STATE] = nstate;
+          sc[X_MU] = mu2; sc[X_NUP] = nu_pen; sc[X_DW] = 0.0; sc[X_STATE] = nstate; sc[X_TEVAL] = 0.0;
           if (status >= 0) sc[X_STATUS] = status;
         }
       }
@@ -690,6 +704,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
         ASC_UNROLL
         for (int i = 0; i < 7; i++) dzp[i] = 0.0;
         double rmax = 0.0, gsum = 0.0, adu = 1.0;
+        double dzK[7] = {0, 0, 0, 0, 0, 0, 0};
         for (int c = 0; c < nch; c++) {
           const int kn = c * CH + role;
           double a_ = 0.5, m_ = 0.5, u_ = 0.0, zb[6] = {1, 1, 1, 1, 1, 1};
@@ -757,6 +772,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             for (int i = 0; i < 8; i++) dzn[i] = outb[i * LDW + col];
             const double id[6] = {rcp(a_), rcp(d.aub - a_), rcp(m_), rcp(1.0 - m_), rcp(u_ + 1.0), rcp(1.0 - u_)};
             const double dza = dzn[IA], dzm = dzn[IM], du = dzn[7];
+            if (kn == K - 1) cpy<7>(dzK, dzn);
             ASC_FTBR(rmax, id[0], dza); ASC_FTBR(rmax, id[1], -dza);
             ASC_FTBR(rmax, id[2], dzm); ASC_FTBR(rmax, id[3], -dzm);
             ASC_FTBR(rmax, id[4], du); ASC_FTBR(rmax, id[5], -du);
@@ -783,6 +799,38 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
           PROF(6);
         }
         rmax = gmax16(rmax); gsum = gsum16(gsum); adu = gmin16(adu);
+        ASC_UNROLL
+        for (int i = 0; i < 7; i++) dzK[i] = gsum16(dzK[i]);          // only the lane of the last node holds non-zeros
+        // ---- the scalars of the step and the step lengths: known once the primal step is (the adjoint below only adds the
+        //      multiplier steps), so that the adjoint phase can evaluate the first trial point of the line search as it goes ----
+        double zK[7];
+        ASC_UNROLL
+        for (int i = 0; i < 7; i++) zK[i] = it[(O_Z + i) * Kp + K - 1];
+        const Terminal tmK = terminal_eval(d, zK);
+        Scal ds;
+        ds.th = dth; ds.nu3 = dnu3;
+        ds.s1 = sc[X_CG1] + tmK.g1g[0] * dzK[IX] + tmK.g1g[1] * dzK[IY];
+        ds.s2 = sc[X_CG2] + tmK.g2g[0] * dzK[IVX] + tmK.g2g[1] * dzK[IVY];
+        ds.nu1 = sig1 * ds.s1 + rs1;
+        ds.nu2 = sig2 * ds.s2 + rs2;
+        ds.zs1 = mu / s.s1 - s.zs1 - s.zs1 / s.s1 * ds.s1;
+        ds.zs2 = mu / s.s2 - s.zs2 - s.zs2 / s.s2 * ds.s2;
+        const double dl_ = s.th - d.tlb, dU = d.tub - s.th;
+        ds.zlt = mu / dl_ - s.zlt - s.zlt / dl_ * ds.th;
+        ds.zut = mu / dU - s.zut + s.zut / dU * ds.th;
+        double apr = 1.0;
+        if (rmax * apr > tau) apr = tau / rmax;
+        ASC_FTB(apr, dl_, ds.th); ASC_FTB(apr, dU, -ds.th);
+        ASC_FTB(apr, s.s1, ds.s1); ASC_FTB(apr, s.s2, ds.s2);
+        ASC_FTB(adu, s.zlt, ds.zlt); ASC_FTB(adu, s.zut, ds.zut);
+        ASC_FTB(adu, s.zs1, ds.zs1); ASC_FTB(adu, s.zs2, ds.zs2);
+        TrialCtx tc;
+        tc.alpha = apr; tc.adu = adu; tc.mlo = mu * 1e-10; tc.mhi = mu * 1e10; tc.hT = hT; tc.first = false;
+        tc.stt = trial_scal(d, s, ds, apr, adu, mu, false);
+        tc.dt = hT * tc.stt.th; tc.be = tc.dt * d.alpha;
+        double *in = w + (size_t)((1 - (int)sc[X_CUR]) * NIT) * Kp;
+        Part P;
+        P.clear();
         // ---- adjoint (backwards over the chunks) ---------------------------------------------------------------------------
         const int rowA2 = (role < 8 ? S_G + role : role < 12 ? S_E + role - 8 : S_G) * LDW;
         const int rowB2 = (role < 7 ? S_R + role : role < 14 ? S_C + role - 7 : S_R) * LDW;
@@ -792,19 +840,18 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
         ASC_UNROLL
         for (int i = 0; i < 7; i++) dln[i] = 0.0;
         double cl = 0.0, ccl = 0.0;
-        double dzK[7] = {0, 0, 0, 0, 0, 0, 0};
-#ifdef PERSIST_DEBUG
-        double dbg_r = 0.0, dbg_dl = 0.0;
-#endif
         for (int c = nch - 1; c >= 0; c--) {
           const int kn = c * CH + role;
           double ccn[7] = {0, 0, 0, 0, 0, 0, 0};
+          NodeIn n, dn;                       // loaded here, used again for the trial point after the sweep of the chunk
           if (kn < K && act) {
-            NodeIn n;
             load_node(it, Kp, K, kn, n);
-            double dz[7];
             ASC_UNROLL
-            for (int i = 0; i < 7; i++) dz[i] = stp[(O_Z + i) * Kp + kn];
+            for (int i = 0; i < 7; i++) { dn.z[i] = stp[(O_Z + i) * Kp + kn]; dn.zp[i] = kn > 0 ? stp[(O_Z + i) * Kp + kn - 1] : 0.0; }
+            dn.u = stp[O_U * Kp + kn];
+            ASC_UNROLL
+            for (int b = 0; b < 6; b++) dn.zb[b] = stp[(O_ZB + b) * Kp + kn];
+            const double *dz = dn.z;
             double G[8], E[4], H[10], F[7], fl[7], ax, ay;
             accel<2>(d, n.z[IX], n.z[IY], n.z[IA], n.z[IM], -cs * n.l[IVX], -cs * n.l[IVY], ax, ay, G, H);
             rhs_f(d, n.z, n.u, ax, ay, F);
@@ -841,7 +888,6 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
               r[IY] -= s.nu3 * tm.e3g[1] + w1 * tm.g1g[1] + tm.e3g[1] * dnu3;
               r[IVX] -= s.nu3 * tm.e3g[2] + w2 * tm.g2g[0] + tm.e3g[2] * dnu3;
               r[IVY] -= s.nu3 * tm.e3g[3] + w2 * tm.g2g[1] + tm.e3g[3] * dnu3;
-              cpy<7>(dzK, dz);
             }
             ASC_UNROLL
             for (int i = 0; i < 8; i++) stage[(S_G + i) * LDW + col] = G[i];
@@ -849,12 +895,6 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             for (int i = 0; i < 4; i++) stage[(S_E + i) * LDW + col] = E[i];
             ASC_UNROLL
             for (int i = 0; i < 7; i++) { stage[(S_R + i) * LDW + col] = r[i]; stage[(S_C + i) * LDW + col] = ccn[i]; }
-            (void)0;
-#ifdef PERSIST_DEBUG
-            for (int i = 0; i < 7; i++) dbg_r = fmax(dbg_r, fabs(r[i]));
-            if (blockIdx.x == 0 && grp == 0 && sc[X_ITERS] == 20.0)
-              for (int i = 0; i < 7; i++) if (fabs(r[i]) > 1e-6) printf("[persist]      adj node %d field %d r %.4e  l %.6e fl %.6e ln %.6e cs %.4e rzraw %.4e mu-term %.4e dz %.3e zb0 %.3e zb1 %.3e zb2 %.3e zb3 %.3e\n", kn, i, r[i], n.l[i], fl[i], n.ln[i], cs, n.l[i] - cs * fl[i] - n.ln[i], i == IA ? mu * (id1 - id0) : i == IM ? mu * (id3 - id2) : 0.0, dz[i], n.zb[0], n.zb[1], n.zb[2], n.zb[3]);
-#endif
           }
           wsync();
           PROF(7);
@@ -876,53 +916,41 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
               for (int i = 0; i < 7; i++) r[i] = rr[i] + dln[i];
               solveAT<0>(G, E, cs, r, dl);
               outb[rowS2 + cj] = hot7.pick(dl);
-#ifdef PERSIST_DEBUG
-              for (int i = 0; i < 7; i++) dbg_dl = fmax(dbg_dl, fabs(dl[i]));
-#endif
               ASC_UNROLL
               for (int i = 0; i < 7; i++) cl += cc[i] * dl[i];
               cpy<7>(dln, dl);
             }
           }
           wsync();
-          if (kn < K && act && live) {
+          if (kn < K && act) {
             ASC_UNROLL
-            for (int i = 0; i < 7; i++) stp[(O_L + i) * Kp + kn] = outb[i * LDW + col];
+            for (int i = 0; i < 7; i++) {
+              dn.l[i] = outb[i * LDW + col];
+              dn.ln[i] = kn + 1 < K ? (role < 15 ? outb[i * LDW + col + 1] : lds_c[grp][i]) : 0.0;
+            }
+            if (live) {
+              ASC_UNROLL
+              for (int i = 0; i < 7; i++) stp[(O_L + i) * Kp + kn] = dn.l[i];
+            }
           }
           wsync();
           PROF(8);
+          // ---- node-parallel: the step of the chunk is complete -> its part of the trial point at the first step length --------
+          if (kn < K && act) {
+            if (role == 0) {
+              ASC_UNROLL
+              for (int i = 0; i < 7; i++) lds_c[grp][i] = dn.l[i];
+            }
+            trial_node(d, K, Kp, kn, n, dn, tc, live, in, P);
+          }
+          PROF(0);
         }
-#ifdef PERSIST_DEBUG
-        dbg_r = gmax16(dbg_r);
-        if (blockIdx.x == 0 && lane == 0) printf("[persist]    newton: dth %.3e dnu3 %.3e max|r_adj| %.3e max|dlam| %.3e rmax %.3e mu %.1e dw %.1e act %d\n", dth, dnu3, dbg_r, dbg_dl, rmax, mu, dw, (int)act);
-#endif
+        P.reduce16();
         // ---- scalars of the step, merit bookkeeping -------------------------------------------------------------------------
         ccl = gsum16(ccl);
-        ASC_UNROLL
-        for (int i = 0; i < 7; i++) dzK[i] = gsum16(dzK[i]);          // only the lane of the last node holds non-zeros
         if (act) {
           cl += ccl;
-          double zK[7];
-          ASC_UNROLL
-          for (int i = 0; i < 7; i++) zK[i] = it[(O_Z + i) * Kp + K - 1];
-          const Terminal tm = terminal_eval(d, zK);
-          Scal ds;
-          ds.th = dth; ds.nu3 = dnu3;
-          ds.s1 = sc[X_CG1] + tm.g1g[0] * dzK[IX] + tm.g1g[1] * dzK[IY];
-          ds.s2 = sc[X_CG2] + tm.g2g[0] * dzK[IVX] + tm.g2g[1] * dzK[IVY];
-          ds.nu1 = sig1 * ds.s1 + rs1;
-          ds.nu2 = sig2 * ds.s2 + rs2;
-          ds.zs1 = mu / s.s1 - s.zs1 - s.zs1 / s.s1 * ds.s1;
-          ds.zs2 = mu / s.s2 - s.zs2 - s.zs2 / s.s2 * ds.s2;
-          const double dl_ = s.th - d.tlb, dU = d.tub - s.th;
-          ds.zlt = mu / dl_ - s.zlt - s.zlt / dl_ * ds.th;
-          ds.zut = mu / dU - s.zut + s.zut / dU * ds.th;
-          double apr = 1.0;
-          if (rmax * apr > tau) apr = tau / rmax;
-          ASC_FTB(apr, dl_, ds.th); ASC_FTB(apr, dU, -ds.th);
-          ASC_FTB(apr, s.s1, ds.s1); ASC_FTB(apr, s.s2, ds.s2);
-          ASC_FTB(adu, s.zlt, ds.zlt); ASC_FTB(adu, s.zut, ds.zut);
-          ASC_FTB(adu, s.zs1, ds.zs1); ASC_FTB(adu, s.zs2, ds.zs2);
+          const Terminal &tm = tmK;
           double gd = mu * gsum;
           gd += ds.th * (1.0 - mu / dl_ + mu / dU) - mu * ds.s1 / s.s1 - mu * ds.s2 / s.s2;
           cl += tm.e3 * (s.nu3 + ds.nu3) + sc[X_CG1] * (s.nu1 + ds.nu1) + sc[X_CG2] * (s.nu2 + ds.nu2);
@@ -940,6 +968,9 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             sc[X_DM] = gd - nu_pen * c1;
             sc[X_PHI0] = s.th - mu * slog + nu_pen * c1;
             sc[X_ALPHA] = apr; sc[X_ADU] = adu; sc[X_LS] = 0.0;
+            sc[X_P + 0] = P.rd; sc[X_P + 1] = P.cinf; sc[X_P + 2] = P.pmin; sc[X_P + 3] = P.pmax; sc[X_P + 4] = P.l1;
+            sc[X_P + 5] = P.zsum; sc[X_P + 6] = P.rth; sc[X_P + 7] = P.c1; sc[X_P + 8] = P.sl;
+            sc[X_TEVAL] = 1.0;
             sc[X_STATE] = ST_TRIAL;
           }
         }
