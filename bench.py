@@ -44,9 +44,15 @@ def algorithmic_flops(levels) -> float:
     return float(sum(it * 4e3 * n for n, it in levels))
 
 
-def coarse_nodes_of(nt: int) -> int:
-    """The automatic coarse grid of the nested iteration (include/ascent.h: ascent_opts.coarse_nodes)."""
-    return max(14, (nt + 5) // 11)
+def nested_levels(nt: int) -> list:
+    """The grids of the automatic nested iteration, finest first (include/ascent.h: ascent_opts.coarse_nodes)."""
+    lv = [nt]
+    while lv[-1] >= 40:
+        c = max(14, (3 * lv[-1] + 5) // 10)
+        if c >= lv[-1]:
+            break
+        lv.append(c)
+    return lv
 
 
 def rank_params(batch: int, rank: int, world: int) -> np.ndarray:
@@ -194,12 +200,16 @@ def main():
         conv_total, conv_all_steps = int(t[0].item()), int(t[1].item())
     if rank == 0:
         k_ms = float(np.mean(kernel_ms))
-        # iterations per grid level: `iters` counts both levels of the nested iteration; an untimed solve of the coarse
-        # grid alone (the same first leg, deterministic) gives the split
-        ntc = coarse_nodes_of(NT)
-        coarse = A.solve_batch_torch(P_t, ntc, tol=max(args.tol, 1e-3), want_traj=False, coarse_nodes=-1, sync=True)   # the coarse leg's tolerance
-        it_c = coarse["iters"].cpu().numpy()
-        levels = [(NT, float((iters - it_c).sum())), (ntc, float(it_c.sum()))]
+        # iterations per grid level: `iters` counts all levels of the nested iteration; untimed solves of the coarser
+        # grids alone (the same first legs, deterministic, at the coarse legs' tolerance) give the split
+        lv = nested_levels(NT)
+        cum = [iters.astype(np.int64)]
+        for n in lv[1:]:
+            sub = A.solve_batch_torch(P_t, n, tol=max(args.tol, 1e-3), want_traj=False, sync=True)
+            cum.append(sub["iters"].cpu().numpy().astype(np.int64))
+        cum.append(np.zeros_like(cum[0]))
+        per_level = [cum[i] - cum[i + 1] for i in range(len(lv))]
+        levels = [(n, float(it.sum())) for n, it in zip(lv, per_level)]
         b_alg = algorithmic_bytes(levels, len(iters), NT)
         f_alg = algorithmic_flops(levels)
         achieved = b_alg / (k_ms * 1e-3) / 1e9
@@ -223,11 +233,11 @@ def main():
                 "workload": ("BASELINE.json configs[2]: 4096-NLP Isp x dry-mass sweep (64x64, Isp 300-320 s, dry mass 2345-2545 kg)"
                              if B == 4096 else f"{B}-NLP sweep per GPU") + ", N=200 nodes, backward Euler (reference NODES=2)",
                 "batch_per_gpu": B, "global_batch": B * world, "n_nodes": NT, "tol": args.tol,
-                "start": f"cold (built-in straight-line guess, mu0=0.1) on a {ntc}-node grid, prolonged to the {NT}-node grid "
+                "start": f"cold (built-in straight-line guess, mu0=0.1) on a {lv[-1]}-node grid, prolonged grid by grid ({' -> '.join(str(n) for n in lv[::-1])} nodes) "
                          "(nested iteration, part of the solver and of the timed step)",
                 "parallelism": f"problem-sharded x{world}, gather only",
                 "iterations_min_mean_max": [int(iters.min()), float(iters.mean()), int(iters.max())],
-                "iterations_mean_by_grid": {str(NT): float((iters - it_c).mean()), str(ntc): float(it_c.mean())},
+                "iterations_mean_by_grid": {str(n): float(it.mean()) for n, it in zip(lv, per_level)},
                 "converged": conv_total, "of": B * world, "converged_over_all_timed_steps": conv_all_steps,
                 "kernel_source_sha16": source_sha16(),
             },

@@ -63,8 +63,10 @@ typedef struct ascent_opts {
                               `angledoubledot` field holds that normalised control u            */
   int32_t coarse_nodes; /* nested iteration for cold starts (warm_start == 0): the NLP is first solved on a coarse
                            grid, that primal-dual solution is prolonged to the n_nodes grid and warm-starts it.
-                           0 = automatic (grids of >= 64 nodes; coarse grid = max(14, (n_nodes+5)/11) nodes,
-                           recursively; coarse levels are solved to max(tol, 1e-3)), -1 = off (single grid),
+                           0 = automatic (grids of >= 40 nodes; coarse grid = max(14, (3 n_nodes + 5)/10) nodes,
+                           recursively: 201 -> 60 -> 18; coarse levels are solved to max(tol, 1e-3); a level
+                           warm-started from the cold-started coarsest grid begins at mu = 1e-6, one warm-started
+                           from a warm-started grid at mu = 1e-8), -1 = off (single grid),
                            > 0 = that many coarse nodes (two levels).
                            iters_out counts the iterations of all levels.                              */
   int32_t terminal;     /* 0 = the reference's terminal speed (:72-78: circular speed of the MEAN radius, imposed at
@@ -160,7 +162,12 @@ int ascent_kkt_step(const ascent_params *p, int64_t batch, const ascent_opts *o,
  * The split paths take schemes 0/1 and formulations 0/1.  For scheme 1 (trapezoid) `defects` is the trapezoid
  * defect and the Hessian block of node k is weighted by -(h*T*tf/2)*(lambda_k + lambda_{k+1}). */
 enum ascent_path { ASCENT_PATH_AUTO = 0, ASCENT_PATH_FUSED = 1, ASCENT_PATH_SPLIT_LANE = 2, ASCENT_PATH_SPLIT_WIDE = 3,
-                   ASCENT_PATH_DENSE = 4 /* d_eval -> d_newton, one wavefront per NLP on dense 8x8 blocks: schemes 0/1/2 */ };
+                   ASCENT_PATH_DENSE = 4, /* d_eval -> d_newton, one wavefront per NLP on dense 8x8 blocks: schemes 0/1/2 */
+                   ASCENT_PATH_PERSIST = 5 /* one round of p_solve, the persistent kernel (ascent_kkt_step_path only: its node
+                                              rows live in LDS; scheme 0, formulation 0) */ };
+/* Which kernels ascent_solve_batch runs for a batch of this size with these options (and the environment overrides):
+ * an ascent_path value, never ASCENT_PATH_AUTO.  No device work. */
+int ascent_default_path(int64_t batch, const ascent_opts *o);
 int ascent_eval_nodes_path(const ascent_params *p, int64_t batch, const ascent_opts *o,
                            const double *iterate, double *defects, double *jac_blocks,
                            double *hess_blocks, int device_id, int path);

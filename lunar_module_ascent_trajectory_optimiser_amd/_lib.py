@@ -32,8 +32,8 @@ class AscentOptsC(C.Structure):
 
 SYMBOLS = ("ascent_version", "ascent_device_count", "ascent_strerror", "ascent_solve_batch",
            "ascent_eval_nodes", "ascent_kkt_step", "ascent_eval_nodes_path", "ascent_kkt_step_path",
-           "ascent_dense_records", "ascent_coast_batch", "ascent_kkt_solve", "ascent_last_kernel_ms")
-PATHS = {"auto": 0, "fused": 1, "split_lane": 2, "split_wide": 3, "dense": 4}     # enum ascent_path
+           "ascent_dense_records", "ascent_coast_batch", "ascent_kkt_solve", "ascent_last_kernel_ms", "ascent_default_path")
+PATHS = {"auto": 0, "fused": 1, "split_lane": 2, "split_wide": 3, "dense": 4, "persist": 5}     # enum ascent_path
 
 _lib = None
 
@@ -74,6 +74,8 @@ def load():
     L.ascent_eval_nodes_path.argtypes = L.ascent_eval_nodes.argtypes + [C.c_int]
     L.ascent_kkt_step_path.restype = C.c_int
     L.ascent_kkt_step_path.argtypes = L.ascent_kkt_step.argtypes + [C.c_int]
+    L.ascent_default_path.restype = C.c_int
+    L.ascent_default_path.argtypes = [C.c_int64, C.POINTER(AscentOptsC)]
     L.ascent_dense_records.restype = C.c_int
     L.ascent_dense_records.argtypes = [C.c_void_p, C.c_int64, C.POINTER(AscentOptsC), C.c_void_p, C.c_void_p, C.c_int]
     L.ascent_kkt_solve.restype = C.c_int

@@ -43,6 +43,7 @@ constexpr int OUT_ROWS = 11;
 enum {
   X_STATE, X_ITERS, X_STATUS, X_CUR, X_FIRST, X_LS, X_MU, X_NUP, X_DW, X_DWL, X_ALPHA, X_ADU, X_PHI0, X_DM, X_C1, X_SL,
   X_RTH, X_DTH, X_DNU3, X_SIG1, X_SIG2, X_RS1, X_RS2, X_CG1, X_CG2,
+  X_PROBE, X_PDW,            // parity probe: one round at the caller's iterate, mu and delta_w, then stop
   X_TEVAL,                   // the trial point of the next round has been evaluated already (by the adjoint phase)
   X_P,                       // 9 reduced partials of that trial point: rd cinf pmin pmax l1 zsum rth c1 sl
   X_PEND = X_P + 8,
@@ -113,7 +114,7 @@ ASC_DEV Scal trial_scal(const Der &d, const Scal &s, const Scal &ds, double alph
 // p_init / p_finish: external blob layouts <-> [NLP][row][node].  Lane = (NLP, node).
 // ==============================================================================================================
 __global__ __launch_bounds__(WAVE) void p_init(const ascent_params *params, long batch, PGeo g, double *ws, const double *guess,
-                                               int warm, double mu_init) {
+                                               int warm, double mu_init, const double *probe_mu, const double *probe_dw) {
   const long p = blockIdx.y;
   const int k = blockIdx.x * WAVE + threadIdx.x, K = g.K, Kp = g.Kp;
   if (k >= Kp) return;
@@ -138,11 +139,14 @@ __global__ __launch_bounds__(WAVE) void p_init(const ascent_params *params, long
     z[IW] = aend / (K * dt0); z[IM] = d.mrate * dt0 * (kk + 1);
     u = 0.0;
   }
-  z[IA] = push_in(z[IA], 0.0, d.aub);
-  z[IM] = push_in(z[IM], 0.0, 1.0);
-  u = push_in(u, -1.0, 1.0);
+  const bool probe = probe_mu != nullptr;          // the iterate is taken as it is
+  if (!probe) {
+    z[IA] = push_in(z[IA], 0.0, d.aub);
+    z[IM] = push_in(z[IM], 0.0, 1.0);
+    u = push_in(u, -1.0, 1.0);
+  }
   ASC_UNROLL
-  for (int b = 0; b < 6; b++) zb[b] = warm == 2 ? fmax(zb[b], 1e-12) : 1.0;
+  for (int b = 0; b < 6; b++) zb[b] = probe ? zb[b] : warm == 2 ? fmax(zb[b], 1e-12) : 1.0;
   ASC_UNROLL
   for (int i = 0; i < 7; i++) l[i] = warm == 2 ? l[i] : 0.0;
   ASC_UNROLL
@@ -162,9 +166,10 @@ __global__ __launch_bounds__(WAVE) void p_init(const ascent_params *params, long
   } else {
     s.th = tf0;
   }
-  s.th = push_in(s.th, d.tlb, d.tub);
+  if (!probe) s.th = push_in(s.th, d.tlb, d.tub);
   const Terminal tm = terminal_eval(d, z);
-  if (warm != 2) {
+  if (probe) {
+  } else if (warm != 2) {
     s.s1 = fmax(tm.g1, 1e-2); s.s2 = fmax(tm.g2, 1e-2);
     s.zlt = s.zut = s.zs1 = s.zs2 = 1.0;
     s.nu3 = s.nu1 = s.nu2 = 0.0;
@@ -177,6 +182,7 @@ __global__ __launch_bounds__(WAVE) void p_init(const ascent_params *params, long
   put_scal(sc, X_S, s);
   sc[X_STATE] = ST_TRIAL; sc[X_FIRST] = 1.0; sc[X_STATUS] = ASCENT_MAX_ITER;
   sc[X_MU] = (asked_warm && !warm) ? 0.1 : mu_init; sc[X_NUP] = 1.0;
+  if (probe) { sc[X_MU] = probe_mu[p]; sc[X_PDW] = probe_dw[p]; sc[X_PROBE] = 1.0; }
 }
 
 __global__ __launch_bounds__(WAVE) void p_finish(const ascent_params *params, long batch, PGeo g, const double *ws, double *traj,
@@ -228,6 +234,28 @@ __global__ __launch_bounds__(WAVE) void p_finish(const ascent_params *params, lo
     ASC_UNROLL
     for (int f = 0; f < 10; f++) traj[((long)f * nt + k + 1) * batch + p] = v[f];
   }
+}
+
+// p_probe_out: the Newton step one probe round left behind, in the external blob layout; inertia[p] = 1: refused
+__global__ __launch_bounds__(WAVE) void p_probe_out(long batch, PGeo g, const double *ws, double *step, int *inertia) {
+  const long p = blockIdx.y;
+  const int k = blockIdx.x * WAVE + threadIdx.x, K = g.K, Kp = g.Kp;
+  if (k >= K) return;
+  const double *w = ws + (size_t)p * g.nlp_doubles();
+  const double *sc = w + (size_t)NROWS * Kp, *stp = w + (size_t)R_ST * Kp;
+  const bool ok = (int)sc[X_STATE] == ST_TRIAL;
+  if (k == 0) {
+    inertia[p] = ok ? 0 : 1;
+    for (int r = 0; r < 10; r++) step[(21L * K + r) * batch + p] = ok ? sc[X_D + r] : 0.0;
+  }
+  ASC_UNROLL
+  for (int i = 0; i < 7; i++) {
+    step[(7L * k + i) * batch + p] = ok ? stp[(O_Z + i) * Kp + k] : 0.0;
+    step[(8L * K + 7L * k + i) * batch + p] = ok ? stp[(O_L + i) * Kp + k] : 0.0;
+  }
+  step[(7L * K + k) * batch + p] = ok ? stp[O_U * Kp + k] : 0.0;
+  ASC_UNROLL
+  for (int b = 0; b < 6; b++) step[(15L * K + 6L * k + b) * batch + p] = ok ? stp[(O_ZB + b) * Kp + k] : 0.0;
 }
 
 // ==============================================================================================================
@@ -431,7 +459,9 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
         zsum += stt.zlt + stt.zut + stt.zs1 + stt.zs2;
         e.sd = fmax(100.0, (l1 + zsum) / (double)(13 * K + 7)) * 0.01;
         int status = -1;
-        if (e.err(0.0) <= tol) { status = ASCENT_CONVERGED; nstate = ST_DONE; }
+        const bool probe = sc[X_PROBE] != 0.0;
+        if (probe) { }
+        else if (e.err(0.0) <= tol) { status = ASCENT_CONVERGED; nstate = ST_DONE; }
         else if ((int)iters >= max_iter) { status = ASCENT_MAX_ITER; nstate = ST_DONE; }
         else {
           while (mu2 > tol * 0.1 && e.err(mu2) <= 10.0 * mu2) {
@@ -443,7 +473,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
         if (role == 0) {
           put_scal(sc, X_S, stt);
           sc[X_CUR] = 1 - cur; sc[X_FIRST] = 0.0; sc[X_ITERS] = iters; sc[X_LS] = 0.0; sc[X_C1] = c1; sc[X_SL] = sl; sc[X_RTH] = rth;
-          sc[X_MU] = mu2; sc[X_NUP] = nu_pen; sc[X_DW] = 0.0; sc[X_STATE] = nstate; sc[X_TEVAL] = 0.0;
+          sc[X_MU] = mu2; sc[X_NUP] = nu_pen; sc[X_DW] = probe ? sc[X_PDW] : 0.0; sc[X_STATE] = nstate; sc[X_TEVAL] = 0.0;
           if (status >= 0) sc[X_STATUS] = status;
         }
       }
@@ -675,7 +705,8 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             sc[X_DWL] = dw; sc[X_STATE] = ST_FACTORED;
           } else {
             const double ndw = next_delta_w(dw, sc[X_DWL]);
-            if (ndw > 1e10) { sc[X_STATUS] = ASCENT_REGULARISATION_FAILED; sc[X_STATE] = ST_DONE; }
+            if (sc[X_PROBE] != 0.0) sc[X_STATE] = ST_DONE;           // a probe reports the refusal
+            else if (ndw > 1e10) { sc[X_STATUS] = ASCENT_REGULARISATION_FAILED; sc[X_STATE] = ST_DONE; }
             else sc[X_DW] = ndw;
           }
         }
@@ -977,6 +1008,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
       }
     }
     wsync();
+    if (sc[X_PROBE] != 0.0) break;
   }
   wsync();
   PROF_END;
@@ -1003,9 +1035,22 @@ int persist_run(const ascent_params *dp, long batch, int K, double *ws, const do
                 size_t errlen) {
   const PGeo g = geo_of(K);
   const dim3 ng((unsigned)((g.Kp + WAVE - 1) / WAVE), (unsigned)batch);
-  hipLaunchKernelGGL(p_init, ng, dim3(WAVE), 0, stream, dp, batch, g, ws, dguess, warm, mu0);
+  hipLaunchKernelGGL(p_init, ng, dim3(WAVE), 0, stream, dp, batch, g, ws, dguess, warm, mu0, (const double *)nullptr, (const double *)nullptr);
   hipLaunchKernelGGL(p_solve, dim3((unsigned)((batch + NPW - 1) / NPW)), dim3(WAVE), 0, stream, dp, batch, g, ws, max_iter, tol);
   hipLaunchKernelGGL(p_finish, ng, dim3(WAVE), 0, stream, dp, batch, g, (const double *)ws, dtraj, dtf, dstatus, diters, dblob);
+  PCHK2(hipGetLastError());
+  return ASCENT_OK;
+}
+
+// One round of p_solve at a caller-supplied iterate (parity surface ascent_kkt_step_path): the iterate as it is, mu and
+// delta_w per problem from the caller; p_probe_out hands back the Newton step.
+int persist_probe(const ascent_params *dp, long batch, int K, double *ws, const double *diterate, const double *dmu, const double *ddw,
+                  double *dstep, int *dinertia, hipStream_t stream, char *err, size_t errlen) {
+  const PGeo g = geo_of(K);
+  const dim3 ng((unsigned)((g.Kp + WAVE - 1) / WAVE), (unsigned)batch);
+  hipLaunchKernelGGL(p_init, ng, dim3(WAVE), 0, stream, dp, batch, g, ws, diterate, 2, 0.1, dmu, ddw);
+  hipLaunchKernelGGL(p_solve, dim3((unsigned)((batch + NPW - 1) / NPW)), dim3(WAVE), 0, stream, dp, batch, g, ws, 1000, -1.0);
+  hipLaunchKernelGGL(p_probe_out, ng, dim3(WAVE), 0, stream, batch, g, (const double *)ws, dstep, dinertia);
   PCHK2(hipGetLastError());
   return ASCENT_OK;
 }

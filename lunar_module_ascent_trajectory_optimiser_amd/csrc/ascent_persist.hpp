@@ -14,4 +14,9 @@ int persist_run(const ascent_params *dp, long batch, int K, double *ws, const do
                 double mu0, double *dtraj, double *dtf, int *dstatus, int *diters, double *dblob, hipStream_t stream, char *err,
                 size_t errlen);
 
+// One interior-point round of the same kernel at a caller-supplied iterate, mu and delta_w (parity surface): the Newton step in
+// the blob layout, inertia[p] = 1 where the factorisation was refused.
+int persist_probe(const ascent_params *dp, long batch, int K, double *ws, const double *diterate, const double *dmu, const double *ddw,
+                  double *dstep, int *dinertia, hipStream_t stream, char *err, size_t errlen);
+
 }  // namespace ascent

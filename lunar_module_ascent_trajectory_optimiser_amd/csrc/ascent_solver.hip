@@ -839,16 +839,19 @@ int hip_fail(hipError_t e, const char *what) {
 #define HIPCHK(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) return hip_fail(e_, #call); } while (0)
 
 // ---------------------------------------------------------------------------------------------
-// Nested iteration (mesh continuation).  A cold start on a grid of >= 64 nodes first solves the same NLP on a
-// grid of about a tenth of the nodes, prolongs that primal-dual solution to the fine grid and warm-starts the
-// fine solve from it with mu0 = 1e-5: on the config-3 sweep 15 coarse + 13 fine iterations instead of 24 fine
-// ones, and hardly any straggler tail.  (The CPU restatement under the test tree follows the same rule, constants
-// and arithmetic, so that iteration counts can be compared one to one.)
+// Nested iteration (mesh continuation).  A cold start on a grid of >= 40 nodes first solves the same NLP on a
+// grid of three tenths of the nodes (recursively: 201 -> 60 -> 18), prolongs that primal-dual solution to the next
+// grid and warm-starts the solve there: with mu0 = 1e-6 from the coarsest (cold-started) grid, with mu0 = 1e-8 from a
+// grid that was itself warm-started.  On the config-3 sweep 9 + 4 + 8 iterations on 17 / 59 / 200 intervals instead
+// of 24 on 200, and hardly any straggler tail (scripts/nested_levels.py compares the policies).  (The CPU
+// restatement under the test tree follows the same rule, constants and arithmetic, so that iteration counts can be
+// compared one to one.)
 // ---------------------------------------------------------------------------------------------
-constexpr int NESTED_MIN_NODES = 64;
-constexpr double NESTED_MU0 = 1e-5;
+constexpr int NESTED_MIN_NODES = 40;
+constexpr double NESTED_MU_FIRST = 1e-6;     // warm start from the cold-started coarsest grid
+constexpr double NESTED_MU_NEXT = 1e-8;      // warm start from a grid that was warm-started itself
 constexpr double NESTED_COARSE_TOL = 1e-3;   // coarse levels: the reference's own OTOL/RTOL (their discretisation error is 1e-2)
-inline int coarse_of(int nt) { const int c = (nt + 5) / 11; return c < 14 ? 14 : c; }
+inline int coarse_of(int nt) { const int c = (3 * nt + 5) / 10; return c < 14 ? 14 : c; }
 
 // Prolongation of external blobs ([row][batch]): linear in tau; node 0 is the fixed initial state (zero, except the
 // algebraic angle of the v1 formulation) for the states and the first node for everything else; bound multipliers
@@ -913,13 +916,19 @@ bool use_dense_path(const ascent_opts *o, int64_t batch) {
   if (o->scheme == 2 || o->solver_path == ASCENT_PATH_DENSE) return true;
   const char *e = getenv("ASCENT_PIPELINE");
   if (e) return !strcmp(e, "dense") && o->formulation == 0;
-  // A handful of NLPs cannot fill even the 16-lane sweeps of the hand-tuned path (one wavefront per four NLPs, serial over
-  // the nodes: ~5 ms at N=200, ~56 ms at N=2000 whatever the batch); the dense-block path with its Newton systems solved by
-  // cyclic reduction over the nodes spreads ONE NLP over hundreds of wavefronts: 3.2 vs 4.8 ms (N=200), 13 vs 56 ms (N=2000)
-  // for a single NLP, break-even near 8 NLPs (scripts/small_batch_paths.py).  ASCENT_SMALL_BATCH=off keeps the hand-tuned path.
+  // A handful of NLPs cannot fill the hand-tuned kernels (one wavefront per four NLPs, serial over the nodes: 3.3 ms at
+  // N=200, 12 ms at N=600, 36-45 ms at N=2000 whatever the batch); the dense-block path with its Newton systems solved by
+  // cyclic reduction over the nodes spreads ONE NLP over hundreds of wavefronts and costs ~1 us per node and NLP on top of
+  // a start-up that grows with log N: 2.8 ms (N=200), 5.2 ms (N=600), 8.8 ms (N=2000) for a single NLP; 4.6 / 8.8 / 24 ms
+  // for eight (scripts/small_batch_paths.py).  Backward Euler: taken while batch <= min(16, intervals/150); the trapezoid
+  // (whose hand-tuned path is the slower split pipeline) keeps the earlier break-even of 8 NLPs.
+  // ASCENT_SMALL_BATCH=off keeps the hand-tuned path.
   const char *sb = getenv("ASCENT_SMALL_BATCH");
   if (sb && !strcmp(sb, "off")) return false;
-  return o->formulation == 0 && batch <= 8 && !getenv("ASCENT_FACTOR") && !getenv("ASCENT_DENSE_NEWTON_OFF");
+  if (o->formulation != 0 || getenv("ASCENT_FACTOR")) return false;
+  const int64_t K = (int64_t)o->n_nodes - 1;
+  const int64_t lim = o->scheme == 1 ? 8 : (K / 150 < 16 ? K / 150 : 16);
+  return batch <= lim;
 }
 
 // The dense-block path solves its Newton systems either by the serial Riccati recursion of one wavefront per NLP or by
@@ -930,7 +939,7 @@ bool use_pcr_newton(int64_t batch) {
   const char *e = getenv("ASCENT_DENSE_NEWTON");
   if (e && !strcmp(e, "pcr")) return true;
   if (e && !strcmp(e, "riccati")) return false;
-  return batch <= 64;      // scripts/small_batch_paths.py: 13.1 vs 15.8 ms at 64 NLPs (N=200), 248 vs 284 ms (N=2000)
+  return batch <= 64;      // scripts/small_batch_paths.py: 11.9 vs 11.9 ms at 64 NLPs (N=200), 163 vs 176 ms (N=2000); 5.8 vs 11.4 at 16
 }
 
 // The persistent kernel (ascent_persist.hip: one wavefront owns four NLPs for the whole solve, node blocks handed from the
@@ -941,7 +950,7 @@ bool use_persist_path(const ascent_opts *o, int64_t batch) {
   if (e) return !strcmp(e, "persist");
   if (getenv("ASCENT_FACTOR")) return false;          // an explicit choice between the split pipeline's sweep kernels
   // measured (scripts/batch_sweep2.py, N=200): 576k NLPs/s at 4096 against 374k for the split pipeline; ahead of every
-  // other path from 9 NLPs up to 24 576 (596k vs 538k fused); the fused kernel takes over at 32 768 (674k vs 603k)
+  // other path from 2 NLPs up to 24 576 (596k vs 538k fused); the fused kernel takes over at 32 768 (674k vs 603k)
   return batch < 28672;
 }
 
@@ -1173,7 +1182,7 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
     const bool fin = l == 0, first = l == nlev - 1;
     const double *g_l = first ? dguess : w.gss;
     const int warm_l = first ? (int)o->warm_start : 2;
-    const double mu_l = first ? mu0 : NESTED_MU0;
+    const double mu_l = first ? mu0 : (l == nlev - 2 ? NESTED_MU_FIRST : NESTED_MU_NEXT);
     const double tol_l = fin ? o->tol : fmax(o->tol, NESTED_COARSE_TOL);
     double *traj_l = fin ? dtraj : nullptr, *tf_l = fin ? dtf : w.tfc, *blob_l = fin ? dblob : w.sol;
     int *st_l = fin ? dstatus : w.st_c, *it_l = fin ? diters : w.it_c;
@@ -1219,9 +1228,10 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
 }
 
 // which kernels a parity-surface call runs: an explicit path, or (AUTO) the one ascent_solve_batch would take
-static int resolve_path(int path, const ascent_opts *o, int64_t batch) {
+static int resolve_path(int path, const ascent_opts *o, int64_t batch, bool steps = false) {
   if (path == ASCENT_PATH_AUTO) {
     if (use_dense_path(o, batch)) return ASCENT_PATH_DENSE;
+    if (steps && use_persist_path(o, batch)) return ASCENT_PATH_PERSIST;      // (the persistent kernel keeps its node rows in LDS)
     const bool split = o->scheme == 1 || o->formulation == 1 || use_split_pipeline(batch);
     if (!split) return ASCENT_PATH_FUSED;
     bool wide = batch <= 4096;
@@ -1229,6 +1239,11 @@ static int resolve_path(int path, const ascent_opts *o, int64_t batch) {
     return wide ? ASCENT_PATH_SPLIT_WIDE : ASCENT_PATH_SPLIT_LANE;
   }
   return path;
+}
+
+int ascent_default_path(int64_t batch, const ascent_opts *o) {
+  if (!o || batch <= 0) return ASCENT_E_ARG;
+  return resolve_path(ASCENT_PATH_AUTO, o, batch, true);
 }
 
 int ascent_eval_nodes_path(const ascent_params *p, int64_t batch, const ascent_opts *o, const double *iterate,
@@ -1281,9 +1296,10 @@ int ascent_kkt_step_path(const ascent_params *p, int64_t batch, const ascent_opt
   int rc = check_common(p, batch, o, device_id);
   if (rc) return rc;
   if (!iterate || !mu || !delta_w || !step || !inertia_out) { snprintf(g_err, sizeof g_err, "null pointer"); return ASCENT_E_ARG; }
-  if (path < ASCENT_PATH_AUTO || path > ASCENT_PATH_DENSE) { snprintf(g_err, sizeof g_err, "unknown path %d", path); return ASCENT_E_ARG; }
-  path = resolve_path(path, o, batch);
+  if (path < ASCENT_PATH_AUTO || path > ASCENT_PATH_PERSIST) { snprintf(g_err, sizeof g_err, "unknown path %d", path); return ASCENT_E_ARG; }
+  path = resolve_path(path, o, batch, true);
   if (o->scheme == 2 && path != ASCENT_PATH_DENSE) { snprintf(g_err, sizeof g_err, "scheme 2 exists in the dense-block path only"); return ASCENT_E_ARG; }
+  if (path == ASCENT_PATH_PERSIST && (o->scheme != 0 || o->formulation != 0)) { snprintf(g_err, sizeof g_err, "the persistent kernel has scheme 0, formulation 0 only"); return ASCENT_E_ARG; }
   if (path == ASCENT_PATH_DENSE && o->formulation != 0) { snprintf(g_err, sizeof g_err, "the dense-block path has formulation 0 only"); return ASCENT_E_ARG; }
   if (path == ASCENT_PATH_FUSED && (o->scheme != 0 || o->formulation != 0)) { snprintf(g_err, sizeof g_err, "the fused path has scheme 0, formulation 0 only"); return ASCENT_E_ARG; }
   std::lock_guard<std::mutex> lock(g_mu[device_id]);
@@ -1293,7 +1309,7 @@ int ascent_kkt_step_path(const ascent_params *p, int64_t batch, const ascent_opt
   const int lpt = lanes_per_tile(batch);
   const bool pcr_probe = path == ASCENT_PATH_DENSE && use_pcr_newton(batch);
   rc = ensure_ws(device_id, path == ASCENT_PATH_DENSE ? (pcr_probe ? dense_pcr_ws_bytes(K, (long)batch) : dense_ws_bytes(K, (long)batch))
-                            : path == ASCENT_PATH_FUSED ? ws_bytes(K, batch, lpt) : pipeline_ws_bytes(K, (long)batch));
+                            : path == ASCENT_PATH_PERSIST ? persist_ws_bytes(K, (long)batch) : path == ASCENT_PATH_FUSED ? ws_bytes(K, batch, lpt) : pipeline_ws_bytes(K, (long)batch));
   if (rc) return rc;
   DevBuf<ascent_params> bp;
   DevBuf<double> bit, bmu, bdw, bst;
@@ -1312,6 +1328,9 @@ int ascent_kkt_step_path(const ascent_params *p, int64_t batch, const ascent_opt
   if (path == ASCENT_PATH_DENSE) {
     rc = dense_probe(bp.d, (long)batch, K, (int)o->scheme, 0, g_ws[device_id].ws, bit.d, bmu.d, bdw.d, true, bst.d, bin.d, nullptr,
                      0, g_err, sizeof g_err, pcr_probe ? 1 : 0);
+    if (rc) return rc;
+  } else if (path == ASCENT_PATH_PERSIST) {
+    rc = persist_probe(bp.d, (long)batch, K, g_ws[device_id].ws, bit.d, bmu.d, bdw.d, bst.d, bin.d, 0, g_err, sizeof g_err);
     if (rc) return rc;
   } else if (path == ASCENT_PATH_FUSED) {
     hipLaunchKernelGGL(k_kkt_step, dim3((unsigned)((batch + lpt - 1) / lpt)), dim3(WAVE), 0, 0, bp.d, (long)batch, lpt, K,

@@ -280,6 +280,13 @@ def solve_batch_torch(params_t, nt: int = 200, tol: float = 1e-9, max_iter: int 
     return out
 
 
+def default_path(batch: int, nt: int = 200, scheme=0, formulation=0) -> str:
+    """The kernels solve_batch runs for a batch of this size (include/ascent.h: ascent_default_path): a key of _lib.PATHS."""
+    o = _opts(nt, 300, 1e-9, 0, 0.0, scheme, formulation)
+    code = _lib.load().ascent_default_path(int(batch), C.byref(o))
+    return {v: k for k, v in _lib.PATHS.items()}[code]
+
+
 def last_kernel_ms(device: int = 0) -> float:
     """HIP-event time of the most recent solve kernel on `device` (waits for it)."""
     return _lib.load().ascent_last_kernel_ms(device)

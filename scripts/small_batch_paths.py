@@ -5,8 +5,8 @@ import numpy as np
 import lunar_module_ascent_trajectory_optimiser_amd as A
 
 print(f"{'nt':>5s} {'B':>4s} {'hand-tuned':>11s} {'dense riccati':>14s} {'dense pcr':>10s}")
-for nt in (200, 2000):
-    for B in (1, 4, 16, 32, 64, 128):
+for nt in (200, 600, 2000):
+    for B in (1, 2, 4, 8, 16, 64):
         P = np.vstack([A.AscentParams().as_row()[None], A.sweep_isp_drymass(16, 8)])[:B]
         row = []
         for path, env in (("auto", None), ("dense", "riccati"), ("dense", "pcr")):

@@ -270,13 +270,20 @@ def test_pcr_newton_variant_and_small_batch_dispatch(coracle, monkeypatch):
                 continue
             res[name] = A.solve_batch(P, ntf, tol=1e-9, scheme=scheme, max_iter=500, path="dense" if name in ("pcr", "riccati") else "auto")
             assert np.all(res[name].status == 0)
+        auto_is_pcr = scheme == 2 or B <= (8 if scheme == 1 else min(16, (ntf - 1) // 150))     # the dispatch rule (ascent_solver.hip)
+        monkeypatch.delenv("ASCENT_SMALL_BATCH", raising=False)
+        assert A.default_path(B, ntf, scheme=scheme) == ("dense" if auto_is_pcr else "persist")
         for name in res:
-            # (cold starts on a 60-node grid run through several inertia corrections, where the PCR variant's curvature rule
-            #  and the exact inertia of the recursions legitimately choose different regularisations: same optimum, other path)
+            # (cold starts and the coarse levels of the nested iteration run through inertia corrections, where the PCR variant's
+            #  curvature rule and the exact inertia of the recursions legitimately choose different regularisations now and
+            #  then: same optimum, a few iterations more or less.  Variants with the same rule take the same path.)
+            same_rule = name == "pcr" or (name == "auto" and auto_is_pcr)
             if ntf >= 200:
-                assert np.array_equal(res[name].iters, res["pcr"].iters), (B, ntf, scheme, name)
+                assert np.array_equal(res[name].iters, res["pcr" if same_rule else "riccati"].iters), (B, ntf, scheme, name)
+                assert np.abs(res[name].iters.astype(int) - res["pcr"].iters).max() <= 4, (B, ntf, scheme, name)
             assert np.abs(res[name].tf - res["pcr"].tf).max() <= (1e-11 if ntf >= 200 else 1e-9)
         if scheme < 2:
             ref = coracle.solve_batch(P, ntf, 500, 1e-9, scheme=scheme)
             coracle.set_scheme(0)
-            assert np.abs(res["auto"].tf - ref["tf"]).max() <= 1e-9 and np.abs(res["auto"].iters.astype(int) - ref["iters"]).max() <= 1
+            assert np.abs(res["riccati"].tf - ref["tf"]).max() <= 1e-9 and np.abs(res["riccati"].iters.astype(int) - ref["iters"]).max() <= 1
+            assert np.abs(res["auto"].tf - ref["tf"]).max() <= 1e-9 and np.abs(res["auto"].iters.astype(int) - ref["iters"]).max() <= 4
