@@ -66,7 +66,7 @@ typedef struct ascent_opts {
                            0 = automatic (grids of >= 40 nodes; coarse grid = max(14, (3 n_nodes + 5)/10) nodes,
                            recursively: 201 -> 60 -> 18; coarse levels are solved to max(tol, 1e-3); a level
                            warm-started from the cold-started coarsest grid begins at mu = 1e-6, one warm-started
-                           from a warm-started grid at mu = 1e-8), -1 = off (single grid),
+                           from a warm-started grid at mu = max(1e-9, tol/100)), -1 = off (single grid),
                            > 0 = that many coarse nodes (two levels).
                            iters_out counts the iterations of all levels.                              */
   int32_t terminal;     /* 0 = the reference's terminal speed (:72-78: circular speed of the MEAN radius, imposed at

@@ -841,15 +841,15 @@ int hip_fail(hipError_t e, const char *what) {
 // ---------------------------------------------------------------------------------------------
 // Nested iteration (mesh continuation).  A cold start on a grid of >= 40 nodes first solves the same NLP on a
 // grid of three tenths of the nodes (recursively: 201 -> 60 -> 18), prolongs that primal-dual solution to the next
-// grid and warm-starts the solve there: with mu0 = 1e-6 from the coarsest (cold-started) grid, with mu0 = 1e-8 from a
-// grid that was itself warm-started.  On the config-3 sweep 9 + 4 + 8 iterations on 17 / 59 / 200 intervals instead
-// of 24 on 200, and hardly any straggler tail (scripts/nested_levels.py compares the policies).  (The CPU
+// grid and warm-starts the solve there: with mu0 = 1e-6 from the coarsest (cold-started) grid, with mu0 = max(1e-9,
+// tol/100) from a grid that was itself warm-started.  On the config-3 sweep 9 + 4 + 8 iterations on 17 / 59 / 200
+// intervals instead of 24 on 200, and hardly any straggler tail (scripts/nested_levels.py compares the policies).  (The CPU
 // restatement under the test tree follows the same rule, constants and arithmetic, so that iteration counts can be
 // compared one to one.)
 // ---------------------------------------------------------------------------------------------
 constexpr int NESTED_MIN_NODES = 40;
 constexpr double NESTED_MU_FIRST = 1e-6;     // warm start from the cold-started coarsest grid
-constexpr double NESTED_MU_NEXT = 1e-8;      // warm start from a grid that was warm-started itself
+inline double nested_mu_next(double tol) { return fmax(1e-9, 1e-2 * tol); }      // warm start from a grid that was warm-started itself (tol: of the finest grid)
 constexpr double NESTED_COARSE_TOL = 1e-3;   // coarse levels: the reference's own OTOL/RTOL (their discretisation error is 1e-2)
 inline int coarse_of(int nt) { const int c = (3 * nt + 5) / 10; return c < 14 ? 14 : c; }
 
@@ -1182,7 +1182,7 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
     const bool fin = l == 0, first = l == nlev - 1;
     const double *g_l = first ? dguess : w.gss;
     const int warm_l = first ? (int)o->warm_start : 2;
-    const double mu_l = first ? mu0 : (l == nlev - 2 ? NESTED_MU_FIRST : NESTED_MU_NEXT);
+    const double mu_l = first ? mu0 : (l == nlev - 2 ? NESTED_MU_FIRST : nested_mu_next(o->tol));
     const double tol_l = fin ? o->tol : fmax(o->tol, NESTED_COARSE_TOL);
     double *traj_l = fin ? dtraj : nullptr, *tf_l = fin ? dtf : w.tfc, *blob_l = fin ? dblob : w.sol;
     int *st_l = fin ? dstatus : w.st_c, *it_l = fin ? diters : w.it_c;

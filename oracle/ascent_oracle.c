@@ -676,13 +676,14 @@ double oracle_kkt_error(const double *params, int nt, const double *blob, double
  * A cold start on a grid of >= 40 nodes first solves the same NLP on a grid of three tenths of the nodes (recursively in
  * the automatic mode: 201 -> 60 -> 18), prolongs that primal-dual solution to the next grid (linear in tau; node 0 is the
  * fixed initial state; bound multipliers scale with the step) and warm-starts the solve there: mu0 = 1e-6 when the guess
- * comes from the cold-started coarsest grid, mu0 = 1e-8 when it comes from a grid that was warm-started itself.  The
+ * comes from the cold-started coarsest grid, mu0 = max(1e-9, tol/100) (tol of the finest grid) when it comes from a grid that
+ * was warm-started itself.  The
  * coarse levels are solved to max(tol, 1e-3) only: their discretisation error is 1e-2.  A problem whose coarse solve does
  * not converge starts cold on the fine grid. */
 static int coarse_of(int nt) { int c = (3 * nt + 5) / 10; return c < 14 ? 14 : c; }
 #define NESTED_MIN_NODES 40
 #define NESTED_MU_FIRST 1e-6
-#define NESTED_MU_NEXT 1e-8
+#define NESTED_MU_NEXT(tol_finest) fmax(1e-9, 1e-2 * (tol_finest))
 #define NESTED_COARSE_TOL 1e-3    /* the coarse levels are solved to the reference's own OTOL/RTOL, not to `tol` */
 
 static void prolong(const double *bc, int Kc, double *bf, int Kf) {
@@ -709,7 +710,7 @@ static void prolong(const double *bc, int Kc, double *bf, int Kf) {
 }
 
 /* blob: out = solution on the nt-grid.  coarse: 0 automatic, -1 single grid, > 0 that many nodes (two levels) */
-static int solve_nested(const oparams *prm, int nt, int max_iter, double tol, int coarse, double *blob, int *iters_out, int *depth_out) {
+static int solve_nested(const oparams *prm, int nt, int max_iter, double tol, double tol_finest, int coarse, double *blob, int *iters_out, int *depth_out) {
   int nc = coarse > 0 ? coarse : coarse_of(nt);
   if (coarse == -1 || (coarse == 0 && nt < NESTED_MIN_NODES) || nc >= nt || nc < 3) {
     if (depth_out) *depth_out = 0;
@@ -717,11 +718,11 @@ static int solve_nested(const oparams *prm, int nt, int max_iter, double tol, in
   }
   double *bc = malloc(BLOB(nc - 1) * 8);
   int itc = 0, itf = 0, depth_c = 0;
-  const int stc = solve_nested(prm, nc, max_iter, fmax(tol, NESTED_COARSE_TOL), coarse > 0 ? -1 : 0, bc, &itc, &depth_c);
+  const int stc = solve_nested(prm, nc, max_iter, fmax(tol, NESTED_COARSE_TOL), tol_finest, coarse > 0 ? -1 : 0, bc, &itc, &depth_c);
   int warm = 0;
   if (stc == ST_CONVERGED) { prolong(bc, nc - 1, blob, nt - 1); warm = 2; }
   free(bc);
-  const int st = solve_one(prm, nt, max_iter, tol, warm, depth_c == 0 ? NESTED_MU_FIRST : NESTED_MU_NEXT, blob, &itf, 0);
+  const int st = solve_one(prm, nt, max_iter, tol, warm, depth_c == 0 ? NESTED_MU_FIRST : NESTED_MU_NEXT(tol_finest), blob, &itf, 0);
   *iters_out = itc + itf;
   if (depth_out) *depth_out = depth_c + 1;
   return st;
@@ -749,7 +750,7 @@ int oracle_solve_batch(const double *params, int batch, int nt, int max_iter, do
       memcpy(blob, guess_blob_or_null + (size_t)b * BLOB(K), BLOB(K) * 8);
       st = solve_one(prm, nt, max_iter, tol, g_warm_mode, g_warm_mu0, blob, &iters, 0);
     } else {
-      st = solve_nested(prm, nt, max_iter, tol, g_coarse, blob, &iters, 0);
+      st = solve_nested(prm, nt, max_iter, tol, tol, g_coarse, blob, &iters, 0);
     }
     status_out[b] = st; iters_out[b] = iters;
     iter_t it; view(blob, K, &it);
