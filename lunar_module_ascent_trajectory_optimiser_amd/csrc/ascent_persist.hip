@@ -43,6 +43,7 @@ constexpr int OUT_ROWS = 11;
 enum {
   X_STATE, X_ITERS, X_STATUS, X_CUR, X_FIRST, X_LS, X_MU, X_NUP, X_DW, X_DWL, X_ALPHA, X_ADU, X_PHI0, X_DM, X_C1, X_SL,
   X_RTH, X_DTH, X_DNU3, X_SIG1, X_SIG2, X_RS1, X_RS2, X_CG1, X_CG2,
+  X_ITB,                     // iterations spent on the coarser grids of the nested iteration
   X_PROBE, X_PDW,            // parity probe: one round at the caller's iterate, mu and delta_w, then stop
   X_TEVAL,                   // the trial point of the next round has been evaluated already (by the adjoint phase)
   X_P,                       // 9 reduced partials of that trial point: rd cinf pmin pmax l1 zsum rth c1 sl
@@ -111,35 +112,20 @@ ASC_DEV Scal trial_scal(const Der &d, const Scal &s, const Scal &ds, double alph
 }
 
 // ==============================================================================================================
-// p_init / p_finish: external blob layouts <-> [NLP][row][node].  Lane = (NLP, node).
+// p_init / p_transfer / p_finish: starting points and results.  Lane = (NLP, node) in p_init and p_transfer.
 // ==============================================================================================================
-__global__ __launch_bounds__(WAVE) void p_init(const ascent_params *params, long batch, PGeo g, double *ws, const double *guess,
-                                               int warm, double mu_init, const double *probe_mu, const double *probe_dw) {
-  const long p = blockIdx.y;
-  const int k = blockIdx.x * WAVE + threadIdx.x, K = g.K, Kp = g.Kp;
-  if (k >= Kp) return;
-  double *w = ws + (size_t)p * g.nlp_doubles();
-  const Der d = derive(params[p]);
-  const int asked_warm = warm;
-  if (warm && !(guess[(21L * K + S_TH) * batch + p] > 0.0)) warm = 0;
-  const double tf0 = 0.9, dr = 0.166, aend = 0.5, vp = sqrt(d.vp2), dt0 = (1.0 / K) * d.T * tf0;
-  const double sdr = sin(dr), cdr = cos(dr);
-  const double xf = -d.rhof * sdr, yf = d.rhof * cdr - d.rho0;
-  double z[7], l[7], zb[6], u;
-  const int kk = k < K ? k : K - 1;                  // padding nodes replicate the last node (never read by anything that counts)
-  if (warm) {
-    ASC_UNROLL
-    for (int i = 0; i < 7; i++) { z[i] = guess[(7L * kk + i) * batch + p]; l[i] = guess[(8L * K + 7L * kk + i) * batch + p]; }
-    u = guess[(7L * K + kk) * batch + p];
-    ASC_UNROLL
-    for (int b = 0; b < 6; b++) zb[b] = guess[(15L * K + 6L * kk + b) * batch + p];
-  } else {
+// The starting point at node kk: the built-in straight-line guess (warm == 0) or the caller's / the coarser grid's values in
+// z, l, u, zb, pushed into the interior (warm 1: primal only, warm 2: primal-dual; a probe takes them as they are)
+ASC_DEV void start_node(const Der &d, int K, int kk, int warm, bool probe, double *z, double *l, double *zb, double &u) {
+  if (!warm) {
+    const double tf0 = 0.9, dr = 0.166, aend = 0.5, vp = sqrt(d.vp2), dt0 = (1.0 / K) * d.T * tf0;
+    const double sdr = sin(dr), cdr = cos(dr);
+    const double xf = -d.rhof * sdr, yf = d.rhof * cdr - d.rho0;
     const double fr = (double)(kk + 1) / K;
     z[IX] = fr * xf; z[IY] = fr * yf; z[IVX] = -fr * vp * cdr; z[IVY] = -fr * vp * sdr; z[IA] = fr * aend;
     z[IW] = aend / (K * dt0); z[IM] = d.mrate * dt0 * (kk + 1);
     u = 0.0;
   }
-  const bool probe = probe_mu != nullptr;          // the iterate is taken as it is
   if (!probe) {
     z[IA] = push_in(z[IA], 0.0, d.aub);
     z[IM] = push_in(z[IM], 0.0, 1.0);
@@ -149,25 +135,12 @@ __global__ __launch_bounds__(WAVE) void p_init(const ascent_params *params, long
   for (int b = 0; b < 6; b++) zb[b] = probe ? zb[b] : warm == 2 ? fmax(zb[b], 1e-12) : 1.0;
   ASC_UNROLL
   for (int i = 0; i < 7; i++) l[i] = warm == 2 ? l[i] : 0.0;
-  ASC_UNROLL
-  for (int i = 0; i < 7; i++) { w[(R_IT + O_Z + i) * Kp + k] = z[i]; w[(R_IT + O_L + i) * Kp + k] = l[i]; }
-  w[(R_IT + O_U) * Kp + k] = u;
-  ASC_UNROLL
-  for (int b = 0; b < 6; b++) w[(R_IT + O_ZB + b) * Kp + k] = zb[b];
-  for (int r = NIT; r < NROWS; r++) w[(size_t)r * Kp + k] = 0.0;          // second iterate buffer, step, gains
-  if (k != K - 1) return;
-  double *sc = w + (size_t)NROWS * Kp;
-  Scal s;
-  if (warm) {
-    const double *gs = guess + (21L * K) * batch + p;
-    s.th = gs[S_TH * batch]; s.zlt = gs[S_ZLT * batch]; s.zut = gs[S_ZUT * batch]; s.s1 = gs[S_S1 * batch];
-    s.s2 = gs[S_S2 * batch]; s.zs1 = gs[S_ZS1 * batch]; s.zs2 = gs[S_ZS2 * batch]; s.nu3 = gs[S_NU3 * batch];
-    s.nu1 = gs[S_NU1 * batch]; s.nu2 = gs[S_NU2 * batch];
-  } else {
-    s.th = tf0;
-  }
+}
+// ... and its scalars (s holds the guess if warm); zK = the last node of the starting point
+ASC_DEV void start_scal(const Der &d, int warm, bool probe, const double *zK, Scal &s) {
+  if (!warm) s.th = 0.9;
   if (!probe) s.th = push_in(s.th, d.tlb, d.tub);
-  const Terminal tm = terminal_eval(d, z);
+  const Terminal tm = terminal_eval(d, zK);
   if (probe) {
   } else if (warm != 2) {
     s.s1 = fmax(tm.g1, 1e-2); s.s2 = fmax(tm.g2, 1e-2);
@@ -178,6 +151,47 @@ __global__ __launch_bounds__(WAVE) void p_init(const ascent_params *params, long
     s.zlt = fmax(s.zlt, 1e-12); s.zut = fmax(s.zut, 1e-12);
     s.zs1 = fmax(s.zs1, 1e-12); s.zs2 = fmax(s.zs2, 1e-12);
   }
+}
+ASC_DEV void store_start(double *w, int Kp, int k, const double *z, const double *l, const double *zb, double u) {
+  ASC_UNROLL
+  for (int i = 0; i < 7; i++) { w[(R_IT + O_Z + i) * Kp + k] = z[i]; w[(R_IT + O_L + i) * Kp + k] = l[i]; }
+  w[(R_IT + O_U) * Kp + k] = u;
+  ASC_UNROLL
+  for (int b = 0; b < 6; b++) w[(R_IT + O_ZB + b) * Kp + k] = zb[b];
+  // (the second iterate buffer, the step and the gains are written before they are read)
+}
+
+__global__ __launch_bounds__(WAVE) void p_init(const ascent_params *params, long batch, PGeo g, double *ws, const double *guess,
+                                               int warm, double mu_init, const double *probe_mu, const double *probe_dw) {
+  const long p = blockIdx.y;
+  const int k = blockIdx.x * WAVE + threadIdx.x, K = g.K, Kp = g.Kp;
+  if (k >= Kp) return;
+  double *w = ws + (size_t)p * g.nlp_doubles();
+  const Der d = derive(params[p]);
+  const int asked_warm = warm;
+  if (warm && !(guess[(21L * K + S_TH) * batch + p] > 0.0)) warm = 0;
+  const bool probe = probe_mu != nullptr;          // the iterate is taken as it is
+  double z[7], l[7], zb[6], u = 0.0;
+  const int kk = k < K ? k : K - 1;                  // padding nodes replicate the last node (never read by anything that counts)
+  if (warm) {
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) { z[i] = guess[(7L * kk + i) * batch + p]; l[i] = guess[(8L * K + 7L * kk + i) * batch + p]; }
+    u = guess[(7L * K + kk) * batch + p];
+    ASC_UNROLL
+    for (int b = 0; b < 6; b++) zb[b] = guess[(15L * K + 6L * kk + b) * batch + p];
+  }
+  start_node(d, K, kk, warm, probe, z, l, zb, u);
+  store_start(w, Kp, k, z, l, zb, u);
+  if (k != K - 1) return;
+  double *sc = w + (size_t)NROWS * Kp;
+  Scal s;
+  if (warm) {
+    const double *gs = guess + (21L * K) * batch + p;
+    s.th = gs[S_TH * batch]; s.zlt = gs[S_ZLT * batch]; s.zut = gs[S_ZUT * batch]; s.s1 = gs[S_S1 * batch];
+    s.s2 = gs[S_S2 * batch]; s.zs1 = gs[S_ZS1 * batch]; s.zs2 = gs[S_ZS2 * batch]; s.nu3 = gs[S_NU3 * batch];
+    s.nu1 = gs[S_NU1 * batch]; s.nu2 = gs[S_NU2 * batch];
+  }
+  start_scal(d, warm, probe, z, s);
   for (int r = 0; r < NSCAL; r++) sc[r] = 0.0;
   put_scal(sc, X_S, s);
   sc[X_STATE] = ST_TRIAL; sc[X_FIRST] = 1.0; sc[X_STATUS] = ASCENT_MAX_ITER;
@@ -185,20 +199,75 @@ __global__ __launch_bounds__(WAVE) void p_init(const ascent_params *params, long
   if (probe) { sc[X_MU] = probe_mu[p]; sc[X_PDW] = probe_dw[p]; sc[X_PROBE] = 1.0; }
 }
 
+// Nested iteration, from one grid to the next finer one without leaving the kernel's own layout: the converged primal-dual
+// solution of the coarse grid (workspace wsc) is prolonged -- linear in tau; node 0 is the fixed initial state for the states
+// and the first node for everything else; bound multipliers scale with the step; scalars are copied: the arithmetic of
+// k_prolong in ascent_solver.hip -- and becomes the primal-dual warm start (mu) of the fine grid (workspace wsf).  A problem whose
+// coarse solve did not converge starts cold.  The iterations spent so far travel along.
+__global__ __launch_bounds__(WAVE) void p_transfer(const ascent_params *params, long batch, PGeo gc, const double *wsc, PGeo gf,
+                                                   double *wsf, double mu) {
+  const long p = blockIdx.y;
+  const int k = blockIdx.x * WAVE + threadIdx.x, Kc = gc.K, Kf = gf.K, Kpc = gc.Kp, Kpf = gf.Kp;
+  if (k >= Kpf) return;
+  const double *wc = wsc + (size_t)p * gc.nlp_doubles(), *scc = wc + (size_t)NROWS * Kpc;
+  double *wf = wsf + (size_t)p * gf.nlp_doubles();
+  const Der d = derive(params[p]);
+  const int warm = (int)scc[X_STATUS] == ASCENT_CONVERGED ? 2 : 0;
+  const double *ic = wc + (size_t)((int)scc[X_CUR] * NIT) * Kpc;
+  double z[7], l[7], zb[6], u = 0.0;
+  const int kk = k < Kf ? k : Kf - 1;
+  if (warm) {
+    const double x = (double)(kk + 1) / (double)Kf * (double)Kc;
+    int j = (int)x;
+    if (j > Kc - 1) j = Kc - 1;
+    const double wt = x - (double)j;
+    const int ja = j ? j - 1 : 0;
+    const double zsc = (double)Kc / (double)Kf;
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) {
+      const double a = j ? ic[(O_Z + i) * Kpc + ja] : 0.0, b = ic[(O_Z + i) * Kpc + j];
+      z[i] = fma(wt, b - a, a);
+      const double la = ic[(O_L + i) * Kpc + ja], lb = ic[(O_L + i) * Kpc + j];
+      l[i] = fma(wt, lb - la, la);
+    }
+    { const double a = ic[O_U * Kpc + ja], b = ic[O_U * Kpc + j]; u = fma(wt, b - a, a); }
+    ASC_UNROLL
+    for (int b6 = 0; b6 < 6; b6++) {
+      const double a = ic[(O_ZB + b6) * Kpc + ja], b = ic[(O_ZB + b6) * Kpc + j];
+      zb[b6] = fma(wt, b - a, a) * zsc;
+    }
+  }
+  start_node(d, Kf, kk, warm, false, z, l, zb, u);
+  store_start(wf, Kpf, k, z, l, zb, u);
+  if (k != Kf - 1) return;
+  double *sc = wf + (size_t)NROWS * Kpf;
+  Scal s;
+  if (warm) s = lds_scal(scc, X_S);
+  start_scal(d, warm, false, z, s);
+  for (int r = 0; r < NSCAL; r++) sc[r] = 0.0;
+  put_scal(sc, X_S, s);
+  sc[X_STATE] = ST_TRIAL; sc[X_FIRST] = 1.0; sc[X_STATUS] = ASCENT_MAX_ITER;
+  sc[X_MU] = warm ? mu : 0.1; sc[X_NUP] = 1.0;
+  sc[X_ITB] = scc[X_ITB] + scc[X_ITERS];
+}
+
+// Results in the external layouts ([field][node][NLP], NLP contiguous).  Lane = NLP, a block = 64 NLPs x one 16-node chunk: the
+// loads gather one 8-byte word per NLP, but the 16 nodes of the chunk come out of the same 128-byte line; the stores are
+// full lines.
 __global__ __launch_bounds__(WAVE) void p_finish(const ascent_params *params, long batch, PGeo g, const double *ws, double *traj,
                                                  double *tf_out, int *status_out, int *iters_out, double *blob) {
-  const long p = blockIdx.y;
-  const int k = blockIdx.x * WAVE + threadIdx.x, K = g.K, Kp = g.Kp, nt = K + 1;
-  if (k >= K) return;
+  const long p = (long)blockIdx.y * WAVE + threadIdx.x;
+  if (p >= batch) return;
+  const int c = blockIdx.x, K = g.K, Kp = g.Kp, nt = K + 1;
   const double *w = ws + (size_t)p * g.nlp_doubles();
   const double *sc = w + (size_t)NROWS * Kp;
   const Der d = derive(params[p]);
   const double *it = w + (size_t)((int)sc[X_CUR] * NIT) * Kp;
-  if (k == 0) {
+  if (c == 0) {
     const Scal s = lds_scal(sc, X_S);
     tf_out[p] = s.th;
     status_out[p] = (int)sc[X_STATUS];
-    iters_out[p] = (int)sc[X_ITERS];
+    iters_out[p] = (int)sc[X_ITERS] + (int)sc[X_ITB];
     if (blob) {
       double *bs = blob + (21L * K) * batch + p;
       bs[S_TH * batch] = s.th; bs[S_ZLT * batch] = s.zlt; bs[S_ZUT * batch] = s.zut; bs[S_S1 * batch] = s.s1;
@@ -213,26 +282,28 @@ __global__ __launch_bounds__(WAVE) void p_finish(const ascent_params *params, lo
       for (int f = 0; f < 10; f++) traj[((long)f * nt) * batch + p] = v[f];
     }
   }
-  double z[7];
-  ASC_UNROLL
-  for (int q = 0; q < 7; q++) z[q] = it[(O_Z + q) * Kp + k];
-  const double u = it[O_U * Kp + k];
-  if (blob) {
+  for (int k = c * CH; k < min(K, (c + 1) * CH); k++) {
+    double z[7];
     ASC_UNROLL
-    for (int q = 0; q < 7; q++) {
-      blob[(7L * k + q) * batch + p] = z[q];
-      blob[(8L * K + 7L * k + q) * batch + p] = it[(O_L + q) * Kp + k];
+    for (int q = 0; q < 7; q++) z[q] = it[(O_Z + q) * Kp + k];
+    const double u = it[O_U * Kp + k];
+    if (blob) {
+      ASC_UNROLL
+      for (int q = 0; q < 7; q++) {
+        blob[(7L * k + q) * batch + p] = z[q];
+        blob[(8L * K + 7L * k + q) * batch + p] = it[(O_L + q) * Kp + k];
+      }
+      blob[(7L * K + k) * batch + p] = u;
+      ASC_UNROLL
+      for (int b = 0; b < 6; b++) blob[(15L * K + 6L * k + b) * batch + p] = it[(O_ZB + b) * Kp + k];
     }
-    blob[(7L * K + k) * batch + p] = u;
-    ASC_UNROLL
-    for (int b = 0; b < 6; b++) blob[(15L * K + 6L * k + b) * batch + p] = it[(O_ZB + b) * Kp + k];
-  }
-  if (traj) {
-    double ax, ay;
-    accel<0>(d, z[IX], z[IY], z[IA], z[IM], 0.0, 0.0, ax, ay, nullptr, nullptr);
-    const double v[10] = {z[IX], z[IY], z[IVX], z[IVY], ax, ay, z[IA], z[IW], u, z[IM]};
-    ASC_UNROLL
-    for (int f = 0; f < 10; f++) traj[((long)f * nt + k + 1) * batch + p] = v[f];
+    if (traj) {
+      double ax, ay;
+      accel<0>(d, z[IX], z[IY], z[IA], z[IM], 0.0, 0.0, ax, ay, nullptr, nullptr);
+      const double v[10] = {z[IX], z[IY], z[IVX], z[IVY], ax, ay, z[IA], z[IW], u, z[IM]};
+      ASC_UNROLL
+      for (int f = 0; f < 10; f++) traj[((long)f * nt + k + 1) * batch + p] = v[f];
+    }
   }
 }
 
@@ -418,7 +489,8 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
           if (k < K) {
             NodeIn n, dn;
             load_node(ic, Kp, K, k, n);
-            load_node(stp, Kp, K, k, dn);
+            if (first) dn = NodeIn{};             // (no step yet; the step rows are not initialised)
+            else load_node(stp, Kp, K, k, dn);
             trial_node(d, K, Kp, k, n, dn, t, live, in, P);
           }
         }
@@ -1033,11 +1105,41 @@ size_t persist_ws_bytes(int K, long batch) { return (size_t)batch * geo_of(K).nl
 int persist_run(const ascent_params *dp, long batch, int K, double *ws, const double *dguess, int warm, int max_iter, double tol,
                 double mu0, double *dtraj, double *dtf, int *dstatus, int *diters, double *dblob, hipStream_t stream, char *err,
                 size_t errlen) {
-  const PGeo g = geo_of(K);
-  const dim3 ng((unsigned)((g.Kp + WAVE - 1) / WAVE), (unsigned)batch);
-  hipLaunchKernelGGL(p_init, ng, dim3(WAVE), 0, stream, dp, batch, g, ws, dguess, warm, mu0, (const double *)nullptr, (const double *)nullptr);
-  hipLaunchKernelGGL(p_solve, dim3((unsigned)((batch + NPW - 1) / NPW)), dim3(WAVE), 0, stream, dp, batch, g, ws, max_iter, tol);
-  hipLaunchKernelGGL(p_finish, ng, dim3(WAVE), 0, stream, dp, batch, g, (const double *)ws, dtraj, dtf, dstatus, diters, dblob);
+  const int levels[1] = {K + 1};
+  return persist_run_nested(dp, batch, levels, 1, ws, dguess, warm, max_iter, tol, tol, mu0, 0.0, 0.0, dtraj, dtf, dstatus, diters, dblob,
+                            stream, err, errlen);
+}
+
+size_t persist_ws_bytes_nested(const int *levels, int nlev, long batch) {
+  size_t b = persist_ws_bytes(levels[0] - 1, batch);
+  if (nlev > 1) b += persist_ws_bytes(levels[1] - 1, batch);
+  return b;
+}
+
+// All grid levels of the nested iteration (levels[0] = the requested grid, finest first; the coarsest is solved first, cold or
+// from the caller's guess): p_init, then per level p_solve and p_transfer to the next finer grid, p_finish at the end.  Two
+// workspace regions alternate between the levels.
+int persist_run_nested(const ascent_params *dp, long batch, const int *levels, int nlev, double *ws, const double *dguess, int warm,
+                       int max_iter, double tol, double tol_coarse, double mu0, double mu_first, double mu_next, double *dtraj,
+                       double *dtf, int *dstatus, int *diters, double *dblob, hipStream_t stream, char *err, size_t errlen) {
+  double *region[2] = {ws, (double *)((char *)ws + ((persist_ws_bytes(levels[0] - 1, batch) + 255) & ~(size_t)255))};
+  PGeo g = geo_of(levels[nlev - 1] - 1);
+  double *w = region[(nlev - 1) & 1];
+  hipLaunchKernelGGL(p_init, dim3((unsigned)((g.Kp + WAVE - 1) / WAVE), (unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g, w, dguess,
+                     warm, mu0, (const double *)nullptr, (const double *)nullptr);
+  for (int l = nlev - 1; l >= 0; l--) {
+    hipLaunchKernelGGL(p_solve, dim3((unsigned)((batch + NPW - 1) / NPW)), dim3(WAVE), 0, stream, dp, batch, g, w, max_iter,
+                       l == 0 ? tol : tol_coarse);
+    if (l > 0) {
+      const PGeo gf = geo_of(levels[l - 1] - 1);
+      double *wf = region[(l - 1) & 1];
+      hipLaunchKernelGGL(p_transfer, dim3((unsigned)((gf.Kp + WAVE - 1) / WAVE), (unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g,
+                         (const double *)w, gf, wf, l == nlev - 1 ? mu_first : mu_next);
+      g = gf; w = wf;
+    }
+  }
+  hipLaunchKernelGGL(p_finish, dim3((unsigned)g.nch, (unsigned)((batch + WAVE - 1) / WAVE)), dim3(WAVE), 0, stream, dp, batch, g,
+                     (const double *)w, dtraj, dtf, dstatus, diters, dblob);
   PCHK2(hipGetLastError());
   return ASCENT_OK;
 }

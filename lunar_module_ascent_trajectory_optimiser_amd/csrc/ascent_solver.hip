@@ -1114,7 +1114,22 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
   const bool pcr = dense && use_pcr_newton(batch);
   const bool persist = !dense && use_persist_path(o, batch);
   const bool split = o->scheme == 1 || o->formulation == 1 || use_split_pipeline(batch);
-  rc = ensure_ws(device_id, persist ? persist_ws_bytes(K, (long)batch) : dense ? (pcr ? dense_pcr_ws_bytes(K, (long)batch) : dense_ws_bytes(K, (long)batch)) : split ? pipeline_ws_bytes(K, (long)batch) : ws_bytes(K, batch, lpt));
+  // grid levels of the nested iteration, finest first (levels[0] = n_nodes); one level = a plain solve
+  int levels[8], nlev = 1;
+  levels[0] = nt;
+  if (o->warm_start == 0 && o->coarse_nodes != -1) {
+    if (o->coarse_nodes > 0) {
+      levels[nlev++] = o->coarse_nodes;
+    } else {
+      for (int n = nt; n >= NESTED_MIN_NODES && nlev < 8;) {
+        const int c = coarse_of(n);
+        if (c >= n) break;
+        levels[nlev++] = c;
+        n = c;
+      }
+    }
+  }
+  rc = ensure_ws(device_id, persist ? persist_ws_bytes_nested(levels, nlev, (long)batch) : dense ? (pcr ? dense_pcr_ws_bytes(K, (long)batch) : dense_ws_bytes(K, (long)batch)) : split ? pipeline_ws_bytes(K, (long)batch) : ws_bytes(K, batch, lpt));
   if (rc) return rc;
   DeviceWs &w = g_ws[device_id];
   const double mu0 = o->mu_init > 0 ? o->mu_init : (o->warm_start ? 1e-4 : 0.1);
@@ -1150,22 +1165,7 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
     dp = w.t_p;
   }
   const unsigned grid = (unsigned)((batch + lpt - 1) / lpt);
-  // grid levels of the nested iteration, finest first (levels[0] = n_nodes); one level = a plain solve
-  int levels[8], nlev = 1;
-  levels[0] = nt;
-  if (o->warm_start == 0 && o->coarse_nodes != -1) {
-    if (o->coarse_nodes > 0) {
-      levels[nlev++] = o->coarse_nodes;
-    } else {
-      for (int n = nt; n >= NESTED_MIN_NODES && nlev < 8;) {
-        const int c = coarse_of(n);
-        if (c >= n) break;
-        levels[nlev++] = c;
-        n = c;
-      }
-    }
-  }
-  if (nlev > 1) {
+  if (nlev > 1 && !persist) {
     size_t n3 = w.int_n, n3b = w.int_n, n3c = w.int_n, ntf = w.int_n;
     rc = grow(w.sol, w.sol_n, (21 * (size_t)(levels[1] - 1) + NSC) * batch);
     if (!rc) rc = grow(w.gss, w.gss_n, rows * batch);
@@ -1177,7 +1177,13 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
     w.int_n = n3;
   }
   HIPCHK(hipEventRecord(w.ev0, stream));
-  for (int l = nlev - 1; l >= 0; l--) {
+  if (persist) {      // all levels inside the kernel's own layout
+    rc = persist_run_nested(dp, (long)batch, levels, nlev, w.ws, dguess, (int)o->warm_start, (int)o->max_iter, o->tol,
+                            fmax(o->tol, NESTED_COARSE_TOL), mu0, NESTED_MU_FIRST, nested_mu_next(o->tol), dtraj, dtf, dstatus, diters,
+                            dblob, stream, g_err, sizeof g_err);
+    if (rc) return rc;
+  }
+  for (int l = nlev - 1; l >= 0 && !persist; l--) {
     const int Kl = levels[l] - 1;
     const bool fin = l == 0, first = l == nlev - 1;
     const double *g_l = first ? dguess : w.gss;
@@ -1189,10 +1195,6 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
     if (dense) {
       rc = dense_run(dp, (long)batch, Kl, (int)o->scheme, 0, w.ws, g_l, warm_l, (int)o->max_iter, tol_l, mu_l, traj_l, tf_l, st_l,
                      it_l, blob_l, stream, g_err, sizeof g_err, pcr ? 1 : 0);
-      if (rc) return rc;
-    } else if (persist) {
-      rc = persist_run(dp, (long)batch, Kl, w.ws, g_l, warm_l, (int)o->max_iter, tol_l, mu_l, traj_l, tf_l, st_l, it_l, blob_l, stream,
-                       g_err, sizeof g_err);
       if (rc) return rc;
     } else if (split) {
       rc = pipeline_run(dp, (long)batch, Kl, (int)o->scheme, (int)o->formulation, w.ws, g_l, warm_l, (int)o->max_iter, tol_l, mu_l,
@@ -1210,7 +1212,7 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
       HIPCHK(hipGetLastError());
     }
   }
-  if (nlev > 1) {
+  if (nlev > 1 && !persist) {
     hipLaunchKernelGGL(k_add_iters, dim3((unsigned)((batch + WAVE - 1) / WAVE)), dim3(WAVE), 0, stream, diters, w.acc, (long)batch);
     HIPCHK(hipGetLastError());
   }
