@@ -49,6 +49,8 @@ def nested_levels(nt: int) -> list:
     lv = [nt]
     while lv[-1] >= 40:
         c = max(14, (3 * lv[-1] + 5) // 10)
+        if c > 17 and 1 <= (c - 1) % 16 <= 3:
+            c -= (c - 1) % 16
         if c >= lv[-1]:
             break
         lv.append(c)

@@ -64,7 +64,7 @@ typedef struct ascent_opts {
   int32_t coarse_nodes; /* nested iteration for cold starts (warm_start == 0): the NLP is first solved on a coarse
                            grid, that primal-dual solution is prolonged to the n_nodes grid and warm-starts it.
                            0 = automatic (grids of >= 40 nodes; coarse grid = max(14, (3 n_nodes + 5)/10) nodes,
-                           recursively: 201 -> 60 -> 18; coarse levels are solved to max(tol, 1e-3); a level
+                           recursively: 201 -> 60 -> 17 -- a grid one to three intervals beyond a multiple of 16 gives them up; coarse levels are solved to max(tol, 1e-3); a level
                            warm-started from the cold-started coarsest grid begins at mu = 1e-6, one warm-started
                            from a warm-started grid at mu = max(1e-9, tol/100)), -1 = off (single grid),
                            > 0 = that many coarse nodes (two levels).

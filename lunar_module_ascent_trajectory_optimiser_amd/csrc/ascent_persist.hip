@@ -251,10 +251,11 @@ __global__ __launch_bounds__(WAVE) void p_transfer(const ascent_params *params, 
   sc[X_ITB] = scc[X_ITB] + scc[X_ITERS];
 }
 
-// Results in the external layouts ([field][node][NLP], NLP contiguous).  Lane = NLP, a block = 64 NLPs x one 16-node chunk: the
-// loads gather one 8-byte word per NLP, but the 16 nodes of the chunk come out of the same 128-byte line; the stores are
-// full lines.
-__global__ __launch_bounds__(WAVE) void p_finish(const ascent_params *params, long batch, PGeo g, const double *ws, double *traj,
+// Results in the external layouts ([field][node][NLP], NLP contiguous).  Lane = NLP, a block = 64 NLPs x one 16-node chunk, one
+// wavefront per FIN_SUB nodes of it: the loads gather one 8-byte word per NLP, but the 16 nodes of the chunk come out of the
+// same 128-byte line (same block, same L1); the stores are full lines.
+constexpr int FIN_WAVES = 8, FIN_SUB = CH / FIN_WAVES;
+__global__ __launch_bounds__(WAVE * FIN_WAVES) void p_finish(const ascent_params *params, long batch, PGeo g, const double *ws, double *traj,
                                                  double *tf_out, int *status_out, int *iters_out, double *blob) {
   const long p = (long)blockIdx.y * WAVE + threadIdx.x;
   if (p >= batch) return;
@@ -263,7 +264,7 @@ __global__ __launch_bounds__(WAVE) void p_finish(const ascent_params *params, lo
   const double *sc = w + (size_t)NROWS * Kp;
   const Der d = derive(params[p]);
   const double *it = w + (size_t)((int)sc[X_CUR] * NIT) * Kp;
-  if (c == 0) {
+  if (c == 0 && threadIdx.y == 0) {
     const Scal s = lds_scal(sc, X_S);
     tf_out[p] = s.th;
     status_out[p] = (int)sc[X_STATUS];
@@ -282,7 +283,7 @@ __global__ __launch_bounds__(WAVE) void p_finish(const ascent_params *params, lo
       for (int f = 0; f < 10; f++) traj[((long)f * nt) * batch + p] = v[f];
     }
   }
-  for (int k = c * CH; k < min(K, (c + 1) * CH); k++) {
+  for (int k = c * CH + threadIdx.y * FIN_SUB; k < min(K, c * CH + (threadIdx.y + 1) * FIN_SUB); k++) {
     double z[7];
     ASC_UNROLL
     for (int q = 0; q < 7; q++) z[q] = it[(O_Z + q) * Kp + k];
@@ -1138,7 +1139,7 @@ int persist_run_nested(const ascent_params *dp, long batch, const int *levels, i
       g = gf; w = wf;
     }
   }
-  hipLaunchKernelGGL(p_finish, dim3((unsigned)g.nch, (unsigned)((batch + WAVE - 1) / WAVE)), dim3(WAVE), 0, stream, dp, batch, g,
+  hipLaunchKernelGGL(p_finish, dim3((unsigned)g.nch, (unsigned)((batch + WAVE - 1) / WAVE)), dim3(WAVE, FIN_WAVES), 0, stream, dp, batch, g,
                      (const double *)w, dtraj, dtf, dstatus, diters, dblob);
   PCHK2(hipGetLastError());
   return ASCENT_OK;

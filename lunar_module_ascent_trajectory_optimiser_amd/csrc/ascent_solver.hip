@@ -840,7 +840,7 @@ int hip_fail(hipError_t e, const char *what) {
 
 // ---------------------------------------------------------------------------------------------
 // Nested iteration (mesh continuation).  A cold start on a grid of >= 40 nodes first solves the same NLP on a
-// grid of three tenths of the nodes (recursively: 201 -> 60 -> 18), prolongs that primal-dual solution to the next
+// grid of three tenths of the nodes (recursively: 201 -> 60 -> 17), prolongs that primal-dual solution to the next
 // grid and warm-starts the solve there: with mu0 = 1e-6 from the coarsest (cold-started) grid, with mu0 = max(1e-9,
 // tol/100) from a grid that was itself warm-started.  On the config-3 sweep 9 + 4 + 8 iterations on 17 / 59 / 200
 // intervals instead of 24 on 200, and hardly any straggler tail (scripts/nested_levels.py compares the policies).  (The CPU
@@ -851,7 +851,15 @@ constexpr int NESTED_MIN_NODES = 40;
 constexpr double NESTED_MU_FIRST = 1e-6;     // warm start from the cold-started coarsest grid
 inline double nested_mu_next(double tol) { return fmax(1e-9, 1e-2 * tol); }      // warm start from a grid that was warm-started itself (tol: of the finest grid)
 constexpr double NESTED_COARSE_TOL = 1e-3;   // coarse levels: the reference's own OTOL/RTOL (their discretisation error is 1e-2)
-inline int coarse_of(int nt) { const int c = (3 * nt + 5) / 10; return c < 14 ? 14 : c; }
+// (three tenths of the nodes; a grid that would spill one to three intervals into another 16-interval chunk of the
+//  persistent kernel gives them up: 18 nodes -> 17)
+inline int coarse_of(int nt) {
+  int c = (3 * nt + 5) / 10;
+  if (c < 14) c = 14;
+  const int over = (c - 1) % 16;
+  if (c > 17 && over >= 1 && over <= 3) c -= over;
+  return c;
+}
 
 // Prolongation of external blobs ([row][batch]): linear in tau; node 0 is the fixed initial state (zero, except the
 // algebraic angle of the v1 formulation) for the states and the first node for everything else; bound multipliers

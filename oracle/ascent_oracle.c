@@ -674,13 +674,19 @@ double oracle_kkt_error(const double *params, int nt, const double *blob, double
 
 /* ---- nested iteration (mesh continuation) ------------------------------------------------------------------
  * A cold start on a grid of >= 40 nodes first solves the same NLP on a grid of three tenths of the nodes (recursively in
- * the automatic mode: 201 -> 60 -> 18), prolongs that primal-dual solution to the next grid (linear in tau; node 0 is the
+ * the automatic mode: 201 -> 60 -> 17), prolongs that primal-dual solution to the next grid (linear in tau; node 0 is the
  * fixed initial state; bound multipliers scale with the step) and warm-starts the solve there: mu0 = 1e-6 when the guess
  * comes from the cold-started coarsest grid, mu0 = max(1e-9, tol/100) (tol of the finest grid) when it comes from a grid that
  * was warm-started itself.  The
  * coarse levels are solved to max(tol, 1e-3) only: their discretisation error is 1e-2.  A problem whose coarse solve does
  * not converge starts cold on the fine grid. */
-static int coarse_of(int nt) { int c = (3 * nt + 5) / 10; return c < 14 ? 14 : c; }
+static int coarse_of(int nt) {      /* one to three intervals beyond a multiple of 16 are given up (18 nodes -> 17): the GPU kernels work in 16-interval chunks */
+  int c = (3 * nt + 5) / 10;
+  if (c < 14) c = 14;
+  const int over = (c - 1) % 16;
+  if (c > 17 && over >= 1 && over <= 3) c -= over;
+  return c;
+}
 #define NESTED_MIN_NODES 40
 #define NESTED_MU_FIRST 1e-6
 #define NESTED_MU_NEXT(tol_finest) fmax(1e-9, 1e-2 * (tol_finest))

@@ -39,7 +39,10 @@ def old_levels(nt):
 def new_levels(nt, num=3, den=10, mn=40):
     lv = [nt]
     while lv[-1] >= mn:
-        lv.append(max(14, (num * lv[-1] + 5) // den))
+        c = max(14, (num * lv[-1] + 5) // den)
+        if c > 17 and 1 <= (c - 1) % 16 <= 3:
+            c -= (c - 1) % 16
+        lv.append(c)
     return lv[::-1]
 
 

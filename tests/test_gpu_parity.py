@@ -179,7 +179,7 @@ def test_split_and_fused_paths_agree(coracle, monkeypatch):
         m = A.solve_batch(S[:5], NT, tol=1e-9, max_iter=4, coarse_nodes=-1)
         assert np.all(m.status == 1) and np.all(m.iters == 4)
         # nested iteration: the cap holds per grid level; a coarse solve that hits it makes the fine one start cold
-        m = A.solve_batch(S[:5], NT, tol=1e-9, max_iter=4)            # three grids: 18 -> 60 -> 200 nodes
+        m = A.solve_batch(S[:5], NT, tol=1e-9, max_iter=4)            # three grids: 17 -> 60 -> 200 nodes
         assert np.all(m.status == 1) and np.all(m.iters == 12)
 
 
@@ -309,7 +309,7 @@ def test_config3_full_size_properties():
     assert np.array_equal(r2.tf, r.tf[perm]) and np.array_equal(r2.iters, r.iters[perm])
 
 
-def test_mesh_refinement_matches_oracle_and_richardson(coracle):
+def test_mesh_refinement_matches_oracle_and_richardson(coracle, monkeypatch):
     """Other grid sizes through the same path: N = 400 against the oracle, and first-order convergence of the
     backward-Euler scheme: 2*t_f(400) - t_f(200) = 435.217 s, the mesh-converged value
     the trapezoid probe gave (435.227 s)."""
@@ -317,8 +317,15 @@ def test_mesh_refinement_matches_oracle_and_richardson(coracle):
     r2, r4 = A.solve_batch(P, 200, tol=1e-9), A.solve_batch(P, 400, tol=1e-9)
     ref = coracle.solve_batch(P.as_row()[None], 400, 300, 1e-9)
     assert r4.status[0] == 0 and ref["status"][0] == 0
-    # (iteration counts: the convergence test of the 36-node coarse level is a rounding-level knife edge, 17 vs 18)
-    assert abs(r4.tf[0] - ref["tf"][0]) <= 1e-9 * ref["tf"][0] and abs(int(r4.iters[0]) - int(ref["iters"][0])) <= 1
+    # (a single NLP on 400 nodes runs on the dense-block path with the PCR Newton solve, whose curvature rule may pick other
+    #  regularisations on the coarse levels than the exact inertia does: a few iterations more or less, same optimum; the
+    #  hand-tuned kernels follow the oracle's rule -- their count is the oracle's up to the rounding knife edge of a
+    #  coarse level's convergence test)
+    assert abs(r4.tf[0] - ref["tf"][0]) <= 1e-9 * ref["tf"][0] and abs(int(r4.iters[0]) - int(ref["iters"][0])) <= 4
+    monkeypatch.setenv("ASCENT_SMALL_BATCH", "off")
+    h4 = A.solve_batch(P, 400, tol=1e-9)
+    monkeypatch.delenv("ASCENT_SMALL_BATCH")
+    assert abs(h4.tf[0] - ref["tf"][0]) <= 1e-9 * ref["tf"][0] and abs(int(h4.iters[0]) - int(ref["iters"][0])) <= 1
     assert abs(r4.final_time()[0] - 434.6222) < 2e-3              # survey probe: 434.62229 s
     assert abs(2 * r4.final_time()[0] - r2.final_time()[0] - 435.217) < 0.02
 
@@ -327,7 +334,7 @@ def test_non_converged_problems_are_flagged():
     """max_iter too small -> status max_iter, never silently 'converged'."""
     r = A.solve_batch(A.sweep_isp_drymass(2, 2), NT, tol=1e-9, max_iter=5, coarse_nodes=-1)
     assert np.all(r.status == 1) and np.all(r.iters == 5)
-    r = A.solve_batch(A.sweep_isp_drymass(2, 2), NT, tol=1e-9, max_iter=5)          # per level: 5 + 5 + 5 (18 -> 60 -> 200 nodes)
+    r = A.solve_batch(A.sweep_isp_drymass(2, 2), NT, tol=1e-9, max_iter=5)          # per level: 5 + 5 + 5 (17 -> 60 -> 200 nodes)
     assert np.all(r.status == 1) and np.all(r.iters == 15)
     # an infeasible problem (far too little thrust) must not report convergence
     bad = A.AscentParams(Ft=3000.0)
