@@ -2,7 +2,7 @@
 import os, sys
 sys.path.insert(0, ".")
 from lunar_module_ascent_trajectory_optimiser_amd import _lib
-_lib.LIB_PATH = os.path.abspath("dbglib/libascent_dbg.so")
+_lib.LIB_PATH = os.path.abspath(os.environ.get("LIB", "dbglib/libascent_dbg.so"))
 import lunar_module_ascent_trajectory_optimiser_amd as A
 S = A.sweep_isp_drymass()[:int(os.environ.get("B", "4096"))]
 os.environ["ASCENT_PIPELINE"] = "persist"
