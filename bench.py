@@ -246,15 +246,17 @@ def main():
             "roofline": {
                 "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                "kernel": ("split pipeline, 16-lane sweeps: q_trial_eval + q_factor_wide (decisions + factorisation; dominant) + q_forward_wide + "
-                           "q_local + q_adjoint_wide, one set per interior-point round" if B <= 4096 else
-                           "split pipeline, one-lane sweeps" if B <= 24576 else "k_solve (fused)"),
+                "kernel": (("p_solve (persistent kernel: one wavefront owns four NLPs for a whole grid level; one launch per grid level, "
+                            f"{len(lv)} levels) + p_init / p_transfer / p_finish") if A.default_path(B, NT) == "persist" else
+                           "k_solve (fused, one lane per NLP), one launch per grid level" if A.default_path(B, NT) == "fused" else
+                           A.default_path(B, NT)),
                 "kernel_ms": k_ms, "algorithmic_bytes_per_launch": b_alg,
                 "fp64_achieved_tflops": f_alg / (k_ms * 1e-3) / 1e12,
                 "fp64_frac": f_alg / (k_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
-                "note": ("kernel_ms = device time of one whole solve (HIP events around all launches of the step); achieved = SURVEY 8d "
-                         "algorithmic bytes of the solve / that time. The node-parallel kernels run at HBM rate; the three serial sweeps are "
-                         "FP64-issue bound (one wavefront per SIMD): see DESIGN.md section 5"),
+                "note": ("kernel_ms = device time of one whole solve (HIP events around all launches of the step; p_solve is 97 % of it: "
+                         "profiles/); achieved = SURVEY 8d algorithmic bytes of the solve (iterations x nodes of every grid level x 2 x 21 "
+                         "doubles + i/o) / that time. The kernel is FP64-issue bound, not HBM bound: one wavefront per SIMD issues one "
+                         "instruction per 4 cycles, and the serial sweeps keep 10 of 16 lanes per NLP busy: see DESIGN.md section 5"),
             },
         }
         if world == 1 and not args.no_continuation:
