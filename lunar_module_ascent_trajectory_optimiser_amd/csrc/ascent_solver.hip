@@ -925,17 +925,17 @@ bool use_dense_path(const ascent_opts *o, int64_t batch) {
   const char *e = getenv("ASCENT_PIPELINE");
   if (e) return !strcmp(e, "dense") && o->formulation == 0;
   // A handful of NLPs cannot fill the hand-tuned kernels (one wavefront per four NLPs, serial over the nodes: 3.3 ms at
-  // N=200, 12 ms at N=600, 36-45 ms at N=2000 whatever the batch); the dense-block path with its Newton systems solved by
+  // N=200, 9 ms at N=600, 31-35 ms at N=2000 for up to 16 NLPs); the dense-block path with its Newton systems solved by
   // cyclic reduction over the nodes spreads ONE NLP over hundreds of wavefronts and costs ~1 us per node and NLP on top of
-  // a start-up that grows with log N: 2.8 ms (N=200), 5.2 ms (N=600), 8.8 ms (N=2000) for a single NLP; 4.6 / 8.8 / 24 ms
-  // for eight (scripts/small_batch_paths.py).  Backward Euler: taken while batch <= min(16, intervals/150); the trapezoid
-  // (whose hand-tuned path is the slower split pipeline) keeps the earlier break-even of 8 NLPs.
+  // a start-up that grows with log N: 3.4 ms (N=200), 4.3 ms (N=600), 8.6 ms (N=2000) for a single NLP; 4.4 / 8.6 / 24 ms
+  // for eight (scripts/small_batch_paths.py).  Backward Euler: taken on grids of >= 400 intervals while batch <=
+  // min(8, intervals/75); the trapezoid (whose hand-tuned path is the slower split pipeline) up to 8 NLPs on any grid.
   // ASCENT_SMALL_BATCH=off keeps the hand-tuned path.
   const char *sb = getenv("ASCENT_SMALL_BATCH");
   if (sb && !strcmp(sb, "off")) return false;
   if (o->formulation != 0 || getenv("ASCENT_FACTOR")) return false;
   const int64_t K = (int64_t)o->n_nodes - 1;
-  const int64_t lim = o->scheme == 1 ? 8 : (K / 150 < 16 ? K / 150 : 16);
+  const int64_t lim = o->scheme == 1 ? 8 : K < 400 ? 0 : (K / 75 < 8 ? K / 75 : 8);
   return batch <= lim;
 }
 
@@ -957,9 +957,10 @@ bool use_persist_path(const ascent_opts *o, int64_t batch) {
   const char *e = getenv("ASCENT_PIPELINE");
   if (e) return !strcmp(e, "persist");
   if (getenv("ASCENT_FACTOR")) return false;          // an explicit choice between the split pipeline's sweep kernels
-  // measured (scripts/batch_sweep2.py, N=200): 576k NLPs/s at 4096 against 374k for the split pipeline; ahead of every
-  // other path from 2 NLPs up to 24 576 (596k vs 538k fused); the fused kernel takes over at 32 768 (674k vs 603k)
-  return batch < 28672;
+  // measured (scripts/batch_sweep2.py, N=200, three-grid nested iteration; persistent | split 16-lane | split one-lane |
+  // fused, k NLPs/s): 16: 4.6 | 3.5 | 2.3 | -; 1024: 246 | 182 | 128 | 49; 4096: 780 | 447 | 359 | 176; 8192: 770 | 483 |
+  // 514 | 302; 16 384: 848 | 502 | 649 | 555; 32 768: 905 | - | 783 | 797; 65 536: 923 | - | 759 | 881: ahead at every size
+  return true;
 }
 
 struct DeviceWs {
