@@ -441,7 +441,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
   __shared__ double stage[S_ROWS * LDW];
   __shared__ double outb[OUT_ROWS * LDW];
   __shared__ double lds_t[NPW][7][7];
-  __shared__ double lds_d[NPW][2][8];
+  __shared__ double lds_d[NPW][3][8];                   // (row 2 stays zero)
   __shared__ double lsc[NPW][NSCAL];
   __shared__ double lds_c[NPW][8];                      // adjoint phase: the multiplier step of the first node of the chunk above
   const int lane = threadIdx.x, grp = lane >> 4, role = lane & 15;
@@ -454,6 +454,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
   double *sc = lsc[grp];
   const Der d = derive(params[pc]);
   for (int r = role; r < NSCAL; r += 16) sc[r] = gsc[r];
+  if (role < 8) lds_d[grp][2][role] = 0.0;
   wsync();
   if (!live && role == 0) sc[X_STATE] = ST_DONE;
   wsync();
@@ -642,7 +643,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             for (int i = 0; i < 10; i++) stage[(S_H + i) * LDW + col] = H[i];
             ASC_UNROLL
             for (int i = 0; i < 7; i++) {
-              stage[(S_F + i) * LDW + col] = F[i];
+              stage[(S_F + i) * LDW + col] = hT * F[i];            // (pre-scaled: the sweep uses hT F only)
               stage[(S_C + i) * LDW + col] = n.z[i] - n.zp[i] - dt * F[i];
               stage[(S_RZ + i) * LDW + col] = n.l[i] - cs * fl[i] - n.ln[i];
               stage[(S_GT + i) * LDW + col] = -hT * fl[i];
@@ -671,9 +672,8 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             const double bza = bcast16<15>(gA), bzm = bcast16<14>(gB);
             const double cc[7] = {bcast16<0>(gB), bcast16<1>(gB), bcast16<2>(gB), bcast16<3>(gB),
                                   bcast16<4>(gB), bcast16<5>(gB), bcast16<6>(gB)};
-            const double rc1[7] = {hT * bcast16<7>(gB), hT * bcast16<8>(gB), hT * bcast16<9>(gB),
-                                   hT * bcast16<10>(gB), hT * bcast16<11>(gB), hT * bcast16<12>(gB),
-                                   hT * bcast16<13>(gB)};
+            const double rc1[7] = {bcast16<7>(gB), bcast16<8>(gB), bcast16<9>(gB), bcast16<10>(gB), bcast16<11>(gB),
+                                   bcast16<12>(gB), bcast16<13>(gB)};
             ASC_UNROLL
             for (int i = 0; i < 7; i++) a[i] += gsgn[i] * gq[i];
             a[IA] += bsc * bza;
@@ -718,7 +718,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             if (rhs) {
               double prc[7];
               ASC_UNROLL
-              for (int i = 0; i < 7; i++) prc[i] = role == 9 ? 0.0 : lds_d[grp][role == 8 ? 1 : 0][i];
+              for (int i = 0; i < 7; i++) prc[i] = lds_d[grp][role - 7][i];
               double uu = 0.0, vv = 0.0;
               ASC_UNROLL
               for (int i = 0; i < 7; i++) {

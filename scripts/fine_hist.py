@@ -1,12 +1,15 @@
-import sys, os
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
+"""Iterations per grid level of the config-3 sweep (default nested iteration): histograms, and how they sit in wavefronts of four."""
+import sys
+sys.path.insert(0, ".")
 import numpy as np
 import lunar_module_ascent_trajectory_optimiser_amd as A
 S = A.sweep_isp_drymass()
-t = A.solve_batch(S, 200, want_traj=False)
-c = A.solve_batch(S, 18, tol=1e-3, want_traj=False, coarse_nodes=-1)
-f = t.iters - c.iters
-print("coarse hist", np.bincount(c.iters)[6:]); print("fine hist", dict(zip(*np.unique(f, return_counts=True))))
-os.environ["ASCENT_DEBUG_ROUNDS"] = "1"
-r = A.solve_batch(S, 200, want_traj=False)
-print("fine-level rounds hist", dict(zip(*np.unique(r.iters, return_counts=True))))
+tot = A.solve_batch(S, 200, tol=1e-9, want_traj=False).iters.astype(int)
+upto60 = A.solve_batch(S, 60, tol=1e-3, want_traj=False).iters.astype(int)
+upto17 = A.solve_batch(S, 17, tol=1e-3, want_traj=False, coarse_nodes=-1).iters.astype(int)
+for name, it in (("17-node level", upto17), ("60-node level", upto60 - upto17), ("200-node level", tot - upto60)):
+    w = it.reshape(-1, 4).max(axis=1)
+    print(f"{name}: hist {np.bincount(it)[it.min():].tolist()} from {it.min()}; mean {it.mean():.2f} max {it.max()}; wavefront maxima: mean {w.mean():.2f} max {w.max()}")
+fine = tot - upto60
+print("fine-level iterations over the 64 x 64 grid (rows: Isp, every 8th; columns: dry mass, every 4th):")
+print(fine.reshape(64, 64)[::8, ::4])
