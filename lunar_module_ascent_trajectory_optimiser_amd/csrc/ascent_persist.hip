@@ -586,7 +586,8 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
                         : role == 14 ? S_SC + 4 : S_SC + 2) * LDW;
       const int rowB = (role < 7 ? S_C + role : role < 14 ? S_F + role - 7 : role == 14 ? S_SC + 3 : S_SC) * LDW;
       const int rowK = (role < 7 ? role : role < 10 ? role : 10) * LDW;      // out rows 0-6 kap, 7-9 k0, 10 dummy
-      const bool colr = role < 7, rhs = role >= 7 && role < 10;
+      const bool colr = role < 7;
+      const int drow = role == 7 ? 0 : role == 8 ? 1 : 2;                   // what a lane subtracts after the pivot: P c, P rc or nothing
       double a[7];
       ASC_UNROLL
       for (int i = 0; i < 7; i++) a[i] = 0.0;
@@ -684,12 +685,10 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             }
             double b[7];
             solveAT<0>(G, E, cs, a, b);
-            if (colr) {
+            if (colr) {       // N <- A^-T N A^-1: the columns, transposed through LDS (in order within a wavefront), the columns again
               ASC_UNROLL
               for (int i = 0; i < 7; i++) lds_t[grp][role][i] = b[i];
-            }
-            wsync();
-            if (colr) {
+              wsync();
               double t[7];
               ASC_UNROLL
               for (int l2 = 0; l2 < 7; l2++) t[l2] = lds_t[grp][l2][role];
@@ -699,14 +698,13 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             ASC_UNROLL
             for (int i = 0; i < 7; i++) mw[i] = bu * bcast16<IB>(b[i]);
             const double D = R0 + dw + bu * mw[IB];
-            if (!(D > 0.0)) bad = 1;
             const double iD = rcp(D);
             const double ru = ru0 + mu * bur, gu = ru0 * ith;
             const double rsel = role == 7 ? ru : role == 8 ? gu : 0.0;
             const double coef = (bu * b[IB] - rsel) * iD;
             ASC_UNROLL
             for (int i = 0; i < 7; i++) a[i] = b[i] - mw[i] * coef;
-            outb[rowK + cj] = coef;
+            outb[rowK + cj] = role < 10 ? coef : D;          // rows 0-6 kap, 7-9 k0, 10: the pivot (for the flush below)
             if (colr) {
               double d0 = 0.0, d1 = 0.0;
               ASC_UNROLL
@@ -715,10 +713,10 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
               lds_d[grp][1][role] = d1;
             }
             wsync();
-            if (rhs) {
+            {     // right-hand-side lanes: a <- a - P c (the column lanes read zeros and keep their a; their U, V are never used)
               double prc[7];
               ASC_UNROLL
-              for (int i = 0; i < 7; i++) prc[i] = lds_d[grp][role - 7][i];
+              for (int i = 0; i < 7; i++) prc[i] = lds_d[grp][drow][i];
               double uu = 0.0, vv = 0.0;
               ASC_UNROLL
               for (int i = 0; i < 7; i++) {
@@ -728,9 +726,6 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
               }
               U += uu; V += vv;
             }
-            const double k00 = bcast16<7>(coef), k01 = bcast16<8>(coef), k02 = bcast16<9>(coef);
-            const double Dk1 = D * k01, Dk2 = D * k02;
-            k10 += Dk1 * k00; k11 += Dk1 * k01; k12 += Dk1 * k02; k20 += Dk2 * k00; k22 += Dk2 * k02;
           }
         }
         wsync();
@@ -738,9 +733,16 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
         // ---- flush the feedback gains of the chunk (node-parallel) ---------------------------------------------------------
         {
           const int k = c * CH + role;
-          if (k < K && act && live) {
-            ASC_UNROLL
-            for (int i = 0; i < 10; i++) w[(size_t)(R_KA + i) * Kp + k] = outb[i * LDW + col];
+          if (k < K && act) {
+            if (live) {
+              ASC_UNROLL
+              for (int i = 0; i < 10; i++) w[(size_t)(R_KA + i) * Kp + k] = outb[i * LDW + col];
+            }
+            // the node's terms of the border's Schur complement and the sign of its pivot (no recurrence: summed here, 16 nodes at a time)
+            const double k00 = outb[7 * LDW + col], k01 = outb[8 * LDW + col], k02 = outb[9 * LDW + col], D = outb[10 * LDW + col];
+            const double Dk1 = D * k01, Dk2 = D * k02;
+            k10 += Dk1 * k00; k11 += Dk1 * k01; k12 += Dk1 * k02; k20 += Dk2 * k00; k22 += Dk2 * k02;
+            if (!(D > 0.0)) bad = 1;
           }
         }
         wsync();
@@ -748,6 +750,8 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
       }
       // ---- border: the 2x2 Schur complement in (theta, nu3); inertia ---------------------------------------------------------
       const double U0 = bcast16<7>(U), U1 = bcast16<8>(U), V1 = bcast16<8>(V), U2 = bcast16<9>(U), V2 = bcast16<9>(V);
+      k10 = gsum16(k10); k11 = gsum16(k11); k12 = gsum16(k12); k20 = gsum16(k20); k22 = gsum16(k22);
+      bad = (int)gmax16((double)bad);
       if (act) {
         const double S10 = k10 + 0.5 * (U0 - V1), S11 = k11 + U1, S12 = k12 + 0.5 * U2, S20 = k20 - 0.5 * V2, S22 = k22;
         int ok = !bad;
