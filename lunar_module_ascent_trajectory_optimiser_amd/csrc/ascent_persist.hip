@@ -803,72 +803,90 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
       const double tau = fmax(0.99, 1.0 - mu);
       // ---- forward -----------------------------------------------------------------------------------------------
       {
-        const int rowA = (role < 8 ? S_G + role : role < 12 ? S_E + role - 8 : role < 15 ? S_K0 + role - 12 : S_G) * LDW;
-        const int rowB = (role < 7 ? S_C + role : role < 14 ? S_F + role - 7 : S_C) * LDW;
-        const int rowC = (role < 7 ? S_KA + role : S_KA) * LDW;
-        const int rowS = (role < 8 ? role : 0) * LDW;
-        const OneHot<8> hot(role);
-        double dzp[7];
-        ASC_UNROLL
-        for (int i = 0; i < 7; i++) dzp[i] = 0.0;
+        // The forward recursion  dz_k = A_k^-1 (dz_{k-1} + x0_k + be du_k e_w),  du_k = du0_k - ka_k . (dz_{k-1} + x0_k)  is affine in
+        // dz_{k-1} with node-local coefficients: dz_k = M_k dz_{k-1} + v_k,  M_k = A_k^-1 - be (A_k^-1 e_w) ka_k'.  The node-parallel
+        // phase forms M_k and v_k (16 nodes at a time); the serial step is then one row of a 6x6 matrix-vector product per lane
+        // (lanes 0-5: x y xdot ydot angle angledot, lane 6: du) -- 6 broadcasts and 7 multiply-adds on a dependency chain of 4
+        // instead of ~90 instructions on a chain of ~25.  The mass component has no feedback (dz_m,k = dz_m,k-1 + x0_m,k): it is a
+        // prefix sum over the nodes, done in the node-parallel phase.
+        const int fbase = (role < 7 ? 7 * role : 0) * LDW;              // rows 7i .. 7i+5: M[i][0..5] (lane 6: -ka), row 7i+6: v[i] (du00)
+        const int fout = (role < 6 ? role : role == 6 ? 7 : 8) * LDW;   // out rows 0-5 dz, 6 dz_m (from the scan), 7 du, 8 dummy
+        double yown = 0.0, carry_m = 0.0;
         double rmax = 0.0, gsum = 0.0, adu = 1.0;
         double dzK[7] = {0, 0, 0, 0, 0, 0, 0};
         for (int c = 0; c < nch; c++) {
           const int kn = c * CH + role;
+          const bool on = kn < K && act;
           double a_ = 0.5, m_ = 0.5, u_ = 0.0, zb[6] = {1, 1, 1, 1, 1, 1};
-          if (kn < K && act) {
-            double z[7], zp[7], F[7], G[8], E[4], ax, ay;
+          double G[8], E[4], x0[7], ka[7], du00 = 0.0;
+          ASC_UNROLL
+          for (int i = 0; i < 7; i++) { x0[i] = 0.0; ka[i] = 0.0; }
+          if (on) {
+            double z[7], zp[7], F[7], ax, ay;
             ASC_UNROLL
             for (int i = 0; i < 7; i++) { z[i] = it[(O_Z + i) * Kp + kn]; zp[i] = kn > 0 ? it[(O_Z + i) * Kp + kn - 1] : 0.0; }
             u_ = it[O_U * Kp + kn];
             a_ = z[IA]; m_ = z[IM];
             ASC_UNROLL
             for (int b = 0; b < 6; b++) zb[b] = it[(O_ZB + b) * Kp + kn];
+            ASC_UNROLL
+            for (int i = 0; i < 7; i++) ka[i] = w[(size_t)(R_KA + i) * Kp + kn];
+            du00 = w[(size_t)R_K0 * Kp + kn] + w[(size_t)(R_K0 + 1) * Kp + kn] * dth + w[(size_t)(R_K0 + 2) * Kp + kn] * dnu3;
             accel<1>(d, z[IX], z[IY], z[IA], z[IM], 0.0, 0.0, ax, ay, G, nullptr);
             rhs_f(d, z, u_, ax, ay, F);
             implicit_block(G, cs, E);
             ASC_UNROLL
-            for (int i = 0; i < 8; i++) stage[(S_G + i) * LDW + col] = G[i];
-            ASC_UNROLL
-            for (int i = 0; i < 4; i++) stage[(S_E + i) * LDW + col] = E[i];
-            ASC_UNROLL
             for (int i = 0; i < 7; i++) {
-              stage[(S_F + i) * LDW + col] = F[i];
-              stage[(S_C + i) * LDW + col] = z[i] - zp[i] - dt * F[i];
+              x0[i] = hT * F[i] * dth - (z[i] - zp[i] - dt * F[i]);
+              du00 -= ka[i] * x0[i];
+            }
+          }
+          // dz_m: inclusive prefix sum of x0_m over the nodes of the NLP (16 here, the chunks before in carry_m)
+          double incl = x0[IM];
+          ASC_UNROLL
+          for (int sft = 1; sft < 16; sft *= 2) {
+            const double t = __shfl_up(incl, sft, 16);
+            if (role >= sft) incl += t;
+          }
+          const double dzm_k = carry_m + incl, dzm_p = dzm_k - x0[IM];
+          carry_m += bcast16<15>(incl);
+          if (on) {
+            const double du00p = du00 - ka[IM] * dzm_p;
+            double Ai[7][7];                  // columns of A^-1
+            ASC_UNROLL
+            for (int j = 0; j < 7; j++) {
+              double e[7];
+              ASC_UNROLL
+              for (int i = 0; i < 7; i++) e[i] = i == j ? 1.0 : 0.0;
+              solveA<0>(G, E, cs, e, Ai[j]);
+            }
+            double ax0[7];
+            solveA<0>(G, E, cs, x0, ax0);
+            ASC_UNROLL
+            for (int i = 0; i < 6; i++) {
+              const double bw = be * Ai[IW][i];
+              ASC_UNROLL
+              for (int j = 0; j < 6; j++) stage[(7 * i + j) * LDW + col] = Ai[j][i] - bw * ka[j];
+              stage[(7 * i + 6) * LDW + col] = ax0[i] + bw * du00p + Ai[IM][i] * dzm_p;
             }
             ASC_UNROLL
-            for (int i = 0; i < 10; i++) stage[(S_KA + i) * LDW + col] = w[(size_t)(R_KA + i) * Kp + kn];
+            for (int j = 0; j < 6; j++) stage[(42 + j) * LDW + col] = -ka[j];
+            stage[48 * LDW + col] = du00p;
+            outb[6 * LDW + col] = dzm_k;
           }
           wsync();
           PROF(4);
           if (act) {
-            for (int jj = 0; jj < CH; jj++) {
-              const int k = c * CH + jj;
-              if (k >= K) continue;
+            const int jn = min(CH, K - c * CH);
+            for (int jj = 0; jj < jn; jj++) {
               const int cj = grp * 16 + jj;
-              const double gA = stage[rowA + cj], gB = stage[rowB + cj], gC = stage[rowC + cj];
-              const double G[8] = {bcast16<0>(gA), bcast16<1>(gA), bcast16<2>(gA), bcast16<3>(gA),
-                                   bcast16<4>(gA), bcast16<5>(gA), bcast16<6>(gA), bcast16<7>(gA)};
-              const double E[4] = {bcast16<8>(gA), bcast16<9>(gA), bcast16<10>(gA), bcast16<11>(gA)};
-              const double k0[3] = {bcast16<12>(gA), bcast16<13>(gA), bcast16<14>(gA)};
-              const double cc[7] = {bcast16<0>(gB), bcast16<1>(gB), bcast16<2>(gB), bcast16<3>(gB),
-                                    bcast16<4>(gB), bcast16<5>(gB), bcast16<6>(gB)};
-              const double F[7] = {bcast16<7>(gB), bcast16<8>(gB), bcast16<9>(gB), bcast16<10>(gB),
-                                   bcast16<11>(gB), bcast16<12>(gB), bcast16<13>(gB)};
-              const double ka[7] = {bcast16<0>(gC), bcast16<1>(gC), bcast16<2>(gC), bcast16<3>(gC),
-                                    bcast16<4>(gC), bcast16<5>(gC), bcast16<6>(gC)};
-              double xi[7], dz[8];
-              double du = k0[0] + k0[1] * dth + k0[2] * dnu3;
-              ASC_UNROLL
-              for (int i = 0; i < 7; i++) {
-                xi[i] = dzp[i] - cc[i] + hT * F[i] * dth;
-                du -= ka[i] * xi[i];
-              }
-              xi[IW] += be * du;
-              solveA<0>(G, E, cs, xi, dz);
-              dz[7] = du;
-              outb[rowS + cj] = hot.pick(dz);
-              cpy<7>(dzp, dz);
+              const double *sj = stage + fbase + cj;
+              const double m0 = sj[0], m1 = sj[LDW], m2 = sj[2 * LDW], m3 = sj[3 * LDW], m4 = sj[4 * LDW], m5 = sj[5 * LDW], vv = sj[6 * LDW];
+              const double b0 = bcast16<0>(yown), b1 = bcast16<1>(yown), b2 = bcast16<2>(yown), b3 = bcast16<3>(yown),
+                           b4 = bcast16<4>(yown), b5 = bcast16<5>(yown);
+              const double e0 = (vv + m0 * b0) + m2 * b2, e1 = m1 * b1 + m3 * b3, e2 = m4 * b4 + m5 * b5;
+              yown = (e0 + e1) + e2;
+              outb[fout + cj] = yown;
             }
           }
           wsync();
@@ -940,13 +958,13 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
         Part P;
         P.clear();
         // ---- adjoint (backwards over the chunks) ---------------------------------------------------------------------------
-        const int rowA2 = (role < 8 ? S_G + role : role < 12 ? S_E + role - 8 : S_G) * LDW;
-        const int rowB2 = (role < 7 ? S_R + role : role < 14 ? S_C + role - 7 : S_R) * LDW;
-        const int rowS2 = (role < 7 ? role : 0) * LDW;
-        const OneHot<7> hot7(role);
-        double dln[7];
-        ASC_UNROLL
-        for (int i = 0; i < 7; i++) dln[i] = 0.0;
+        // The adjoint recursion  dl_k = A_k^-T (r_k + dl_{k+1})  in the same affine form: dl_k = N_k dl_{k+1} + w_k with the node-local
+        // N_k = A_k^-T and w_k = A_k^-T r_k.  Columns angledot and mass of A^-T are unit vectors (rows angledot and mass of A are), so a
+        // lane needs five coefficients, its own previous value (lanes 5 and 6) and w: rows 6i .. 6i+4: N[i][0..4], row 6i+5: w[i].
+        const int abase = (role < 7 ? 6 * role : 0) * LDW;
+        const int aout = (role < 7 ? role : 8) * LDW;
+        const double aself = (role == IW || role == IM) ? 1.0 : 0.0;
+        double lown = 0.0;
         double cl = 0.0, ccl = 0.0;
         for (int c = nch - 1; c >= 0; c--) {
           const int kn = c * CH + role;
@@ -997,36 +1015,32 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
               r[IVX] -= s.nu3 * tm.e3g[2] + w2 * tm.g2g[0] + tm.e3g[2] * dnu3;
               r[IVY] -= s.nu3 * tm.e3g[3] + w2 * tm.g2g[1] + tm.e3g[3] * dnu3;
             }
+            double wv[7];
+            solveAT<0>(G, E, cs, r, wv);
             ASC_UNROLL
-            for (int i = 0; i < 8; i++) stage[(S_G + i) * LDW + col] = G[i];
+            for (int j = 0; j < 5; j++) {
+              double e[7], cT[7];             // column j of A^-T
+              ASC_UNROLL
+              for (int i = 0; i < 7; i++) e[i] = i == j ? 1.0 : 0.0;
+              solveAT<0>(G, E, cs, e, cT);
+              ASC_UNROLL
+              for (int i = 0; i < 7; i++) stage[(6 * i + j) * LDW + col] = cT[i];
+            }
             ASC_UNROLL
-            for (int i = 0; i < 4; i++) stage[(S_E + i) * LDW + col] = E[i];
-            ASC_UNROLL
-            for (int i = 0; i < 7; i++) { stage[(S_R + i) * LDW + col] = r[i]; stage[(S_C + i) * LDW + col] = ccn[i]; }
+            for (int i = 0; i < 7; i++) stage[(6 * i + 5) * LDW + col] = wv[i];
           }
           wsync();
           PROF(7);
           if (act) {
-            for (int jj = CH - 1; jj >= 0; jj--) {
-              const int k = c * CH + jj;
-              if (k >= K) continue;
+            const int jj0 = min(CH, K - c * CH) - 1;
+            for (int jj = jj0; jj >= 0; jj--) {
               const int cj = grp * 16 + jj;
-              const double gA = stage[rowA2 + cj], gB = stage[rowB2 + cj];
-              const double G[8] = {bcast16<0>(gA), bcast16<1>(gA), bcast16<2>(gA), bcast16<3>(gA),
-                                   bcast16<4>(gA), bcast16<5>(gA), bcast16<6>(gA), bcast16<7>(gA)};
-              const double E[4] = {bcast16<8>(gA), bcast16<9>(gA), bcast16<10>(gA), bcast16<11>(gA)};
-              const double rr[7] = {bcast16<0>(gB), bcast16<1>(gB), bcast16<2>(gB), bcast16<3>(gB),
-                                    bcast16<4>(gB), bcast16<5>(gB), bcast16<6>(gB)};
-              const double cc[7] = {bcast16<7>(gB), bcast16<8>(gB), bcast16<9>(gB), bcast16<10>(gB),
-                                    bcast16<11>(gB), bcast16<12>(gB), bcast16<13>(gB)};
-              double r[7], dl[7];
-              ASC_UNROLL
-              for (int i = 0; i < 7; i++) r[i] = rr[i] + dln[i];
-              solveAT<0>(G, E, cs, r, dl);
-              outb[rowS2 + cj] = hot7.pick(dl);
-              ASC_UNROLL
-              for (int i = 0; i < 7; i++) cl += cc[i] * dl[i];
-              cpy<7>(dln, dl);
+              const double *sj = stage + abase + cj;
+              const double n0 = sj[0], n1 = sj[LDW], n2 = sj[2 * LDW], n3 = sj[3 * LDW], n4 = sj[4 * LDW], wv = sj[5 * LDW];
+              const double b0 = bcast16<0>(lown), b1 = bcast16<1>(lown), b2 = bcast16<2>(lown), b3 = bcast16<3>(lown), b4 = bcast16<4>(lown);
+              const double e0 = (wv + aself * lown) + n0 * b0, e1 = n1 * b1 + n2 * b2, e2 = n3 * b3 + n4 * b4;
+              lown = (e0 + e1) + e2;
+              outb[aout + cj] = lown;
             }
           }
           wsync();
@@ -1035,6 +1049,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             for (int i = 0; i < 7; i++) {
               dn.l[i] = outb[i * LDW + col];
               dn.ln[i] = kn + 1 < K ? (role < 15 ? outb[i * LDW + col + 1] : lds_c[grp][i]) : 0.0;
+              ccl += ccn[i] * dn.l[i];            // c . dlambda: no recurrence, summed here
             }
             if (live) {
               ASC_UNROLL
