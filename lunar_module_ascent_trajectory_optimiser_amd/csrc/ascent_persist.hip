@@ -349,6 +349,16 @@ ASC_DEV void load_node(const double *it, int Kp, int K, int k, NodeIn &n) {
   for (int b = 0; b < 6; b++) n.zb[b] = it[(O_ZB + b) * Kp + k];
 }
 
+// Rows xdot and ydot of A^-1, A = I - dt df/dz (see solveA in ascent_device.hpp).  The other rows follow from them:
+// row x = e_x + dt row xdot, row y = e_y + dt row ydot, row angle = e_angle + dt e_angledot; rows angledot and mass are unit vectors.
+ASC_DEV void ainv_vrows(const double *G, const double *E, double dt, double *rvx, double *rvy) {
+  double c1[7], c2[7];
+  c1[IX] = dt * G[0]; c1[IY] = dt * G[1]; c1[IVX] = 1.0; c1[IVY] = 0.0; c1[IA] = dt * G[2]; c1[IW] = dt * c1[IA]; c1[IM] = dt * G[3];
+  c2[IX] = dt * G[4]; c2[IY] = dt * G[5]; c2[IVX] = 0.0; c2[IVY] = 1.0; c2[IA] = dt * G[6]; c2[IW] = dt * c2[IA]; c2[IM] = dt * G[7];
+  ASC_UNROLL
+  for (int i = 0; i < 7; i++) { rvx[i] = E[0] * c1[i] + E[1] * c2[i]; rvy[i] = E[2] * c1[i] + E[3] * c2[i]; }
+}
+
 // Partial sums of the merit function and the KKT error over the nodes a lane evaluates
 struct Part {
   double rd, cinf, pmin, pmax, l1, zsum, rth, c1, sl;
@@ -852,22 +862,34 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
           carry_m += bcast16<15>(incl);
           if (on) {
             const double du00p = du00 - ka[IM] * dzm_p;
-            double Ai[7][7];                  // columns of A^-1
-            ASC_UNROLL
-            for (int j = 0; j < 7; j++) {
-              double e[7];
+            double rvx[7], rvy[7];
+            ainv_vrows(G, E, cs, rvx, rvy);
+            // row i of M = (row i of A^-1) - be aW[i] ka',  v[i] = (row i of A^-1) . x0 + be aW[i] du00' + A^-1[i][m] dz_m,k-1,  aW = A^-1 e_w
+            auto emit = [&](int i, const double *r, double aw) {
+              const double bw = be * aw;
+              double v = bw * du00p + r[IM] * dzm_p;
               ASC_UNROLL
-              for (int i = 0; i < 7; i++) e[i] = i == j ? 1.0 : 0.0;
-              solveA<0>(G, E, cs, e, Ai[j]);
-            }
-            double ax0[7];
-            solveA<0>(G, E, cs, x0, ax0);
-            ASC_UNROLL
-            for (int i = 0; i < 6; i++) {
-              const double bw = be * Ai[IW][i];
+              for (int j = 0; j < 7; j++) v += r[j] * x0[j];
               ASC_UNROLL
-              for (int j = 0; j < 6; j++) stage[(7 * i + j) * LDW + col] = Ai[j][i] - bw * ka[j];
-              stage[(7 * i + 6) * LDW + col] = ax0[i] + bw * du00p + Ai[IM][i] * dzm_p;
+              for (int j = 0; j < 6; j++) stage[(7 * i + j) * LDW + col] = r[j] - bw * ka[j];
+              stage[(7 * i + 6) * LDW + col] = v;
+            };
+            emit(IVX, rvx, rvx[IW]);
+            emit(IVY, rvy, rvy[IW]);
+            {
+              double r[7];
+              ASC_UNROLL
+              for (int j = 0; j < 7; j++) r[j] = (j == IX ? 1.0 : 0.0) + cs * rvx[j];
+              emit(IX, r, cs * rvx[IW]);
+              ASC_UNROLL
+              for (int j = 0; j < 7; j++) r[j] = (j == IY ? 1.0 : 0.0) + cs * rvy[j];
+              emit(IY, r, cs * rvy[IW]);
+              ASC_UNROLL
+              for (int j = 0; j < 7; j++) r[j] = j == IA ? 1.0 : j == IW ? cs : 0.0;
+              emit(IA, r, cs);
+              ASC_UNROLL
+              for (int j = 0; j < 7; j++) r[j] = j == IW ? 1.0 : 0.0;
+              emit(IW, r, 1.0);
             }
             ASC_UNROLL
             for (int j = 0; j < 6; j++) stage[(42 + j) * LDW + col] = -ka[j];
@@ -1017,14 +1039,17 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             }
             double wv[7];
             solveAT<0>(G, E, cs, r, wv);
-            ASC_UNROLL
-            for (int j = 0; j < 5; j++) {
-              double e[7], cT[7];             // column j of A^-T
+            {     // N = A^-T: N[i][j] = A^-1[j][i], j = x y xdot ydot angle (the rows of A^-1 above)
+              double rvx[7], rvy[7];
+              ainv_vrows(G, E, cs, rvx, rvy);
               ASC_UNROLL
-              for (int i = 0; i < 7; i++) e[i] = i == j ? 1.0 : 0.0;
-              solveAT<0>(G, E, cs, e, cT);
-              ASC_UNROLL
-              for (int i = 0; i < 7; i++) stage[(6 * i + j) * LDW + col] = cT[i];
+              for (int i = 0; i < 7; i++) {
+                stage[(6 * i + IVX) * LDW + col] = rvx[i];
+                stage[(6 * i + IVY) * LDW + col] = rvy[i];
+                stage[(6 * i + IX) * LDW + col] = (i == IX ? 1.0 : 0.0) + cs * rvx[i];
+                stage[(6 * i + IY) * LDW + col] = (i == IY ? 1.0 : 0.0) + cs * rvy[i];
+                stage[(6 * i + IA) * LDW + col] = i == IA ? 1.0 : i == IW ? cs : 0.0;
+              }
             }
             ASC_UNROLL
             for (int i = 0; i < 7; i++) stage[(6 * i + 5) * LDW + col] = wv[i];
