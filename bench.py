@@ -121,8 +121,8 @@ def cpu_baseline(params: np.ndarray, nt: int, tol: float, sample: int):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-per-gpu", type=int, default=4096)
     ap.add_argument("--tol", type=float, default=1e-9)
     ap.add_argument("--cpu-sample", type=int, default=2048)
