@@ -121,10 +121,11 @@ const char *ascent_strerror(int code);
  * traj_out [10*n_nodes][batch], tf_out/status_out/iters_out [batch]; sol_blob_out_or_null
  * [21K+10][batch] receives the full primal-dual solution (usable as a warm start).
  * stream: hipStream_t or NULL.  With host pointers the call returns after the results are in the
- * caller's buffers.  With ptr_is_device != 0 and a stream, large batches (fused kernel, > 24 576 NLPs,
- * scheme 0 / formulation 0) are only enqueued; smaller batches (split pipeline; also every scheme-1 or
- * formulation-1 batch) synchronise the stream once per burst of four interior-point rounds, because the
- * host steers the rounds, and return with the last kernels enqueued.
+ * caller's buffers.  With ptr_is_device != 0 and a stream, the persistent kernel (scheme 0, formulation 0: the
+ * default at every batch size; ascent_default_path) is only enqueued -- a handful of launches per grid level, no
+ * host involvement; the split pipeline (scheme 1 / formulation 1) and the dense-block path (scheme 2, a few NLPs
+ * on long grids) synchronise the stream once per burst of interior-point rounds, because the host steers the
+ * rounds, and return with the last kernels enqueued.
  * Concurrency: the library keeps ONE workspace per device.  Calls on the same device are serialised on the
  * host by a mutex, and a call whose predecessor on that device is still executing (asynchronous device-
  * pointer calls on different streams) makes its stream wait for the predecessor's last kernel first
