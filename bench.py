@@ -128,6 +128,7 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-continuation", action="store_true", help="skip the secondary warm-start (continuation) measurement")
+    ap.add_argument("--no-other-configs", action="store_true", help="skip the secondary lines for BASELINE configs 1, 4 (one shard) and 5")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo for a CPU rehearsal of the gather)")
     args = ap.parse_args()
 
@@ -279,6 +280,33 @@ def main():
                 "max_abs_tf_diff_vs_cold": float((wout["tf"] - out["tf"]).abs().max().item()),
                 "policy": "primal-dual warm start of every NLP from the nominal Apollo-11 solution, mu0=1e-6; not the headline value",
             }
+        if world == 1 and not args.no_other_configs and B == 4096:
+            # Secondary lines (never `value`): the other BASELINE.json configurations that fit one GPU, each timed over 3 solves
+            def timed(fn, n=3):
+                fn()
+                ms = []
+                for _ in range(n):
+                    r = fn()
+                    ms.append(r.kernel_ms)
+                return r, float(np.mean(ms))
+            oc = {}
+            r1, ms1 = timed(lambda: A.solve_batch(A.AscentParams(), NT, tol=args.tol))
+            oc["config1_single_nlp"] = {"ms_per_solve": ms1, "converged": int((r1.status == 0).sum()), "iterations": int(r1.iters[0]),
+                                        "final_time_s": float(r1.final_time()[0]), "path": A.default_path(1, NT),
+                                        "what": "the reference's own problem (Apollo 11, N=200, backward Euler), cold start"}
+            S4 = np.ascontiguousarray(A.sweep_config4()[:32768])
+            r4, ms4 = timed(lambda: A.solve_batch(S4, NT, tol=args.tol, want_traj=False))
+            oc["config4_shard0"] = {"value": float((r4.status == 0).sum()) / (ms4 * 1e-3), "unit": "NLPs/s", "ms_per_solve": ms4,
+                                    "converged": int((r4.status == 0).sum()), "of": 32768, "path": A.default_path(32768, NT),
+                                    "iterations_min_mean_max": [int(r4.iters.min()), float(r4.iters.mean()), int(r4.iters.max())],
+                                    "what": "first contiguous 32768-NLP shard of the 262144-problem box (one GPU's share at 8 GPUs), no trajectories returned"}
+            r5, ms5 = timed(lambda: A.solve_batch(A.AscentParams(), 2000, tol=args.tol, scheme=2, terminal="ellipse", max_iter=500))
+            o5 = r5.orbit()
+            oc["config5_single_nlp"] = {"ms_per_solve": ms5, "converged": int((r5.status == 0).sum()), "iterations": int(r5.iters[0]),
+                                        "final_time_s": float(r5.final_time()[0]), "path": A.default_path(1, 2000, scheme=2),
+                                        "orbit_periapsis_apoapsis_alt_m": [float(o5["periapsis_alt"][0]), float(o5["apoapsis_alt"][0])],
+                                        "what": "N=2000 Hermite-Simpson, terminal condition of the (r_peri, r_apo) ellipse, Kepler coast on the device; angular-acceleration bound active"}
+            line["other_configs"] = oc
         if world == 1 and not args.no_cpu_baseline:
             cb, idx, res = cpu_baseline(P, NT, args.tol, min(args.cpu_sample, B))
             tf_cpu = np.concatenate([r["tf"] for r in res])
