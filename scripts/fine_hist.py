@@ -13,3 +13,9 @@ for name, it in (("17-node level", upto17), ("60-node level", upto60 - upto17), 
 fine = tot - upto60
 print("fine-level iterations over the 64 x 64 grid (rows: Isp, every 8th; columns: dry mass, every 4th):")
 print(fine.reshape(64, 64)[::8, ::4])
+# what a single launch over all levels could gain: sum over levels of the slowest wavefront vs the slowest sum
+cost = {17: 1.0 * 16, 60: 1.0 * 64, 200: 1.0 * 208}      # node-rounds per round (chunks x 16)
+lv = {17: upto17, 60: upto60 - upto17, 200: tot - upto60}
+wave = {n: (it + 1).reshape(-1, 4).max(axis=1) * cost[n] for n, it in lv.items()}
+a = sum(w.max() for w in wave.values()); b = (wave[17] + wave[60] + wave[200]).max(); m = (wave[17] + wave[60] + wave[200]).mean()
+print(f"sum of per-level maxima {a:.0f}, maximum of per-wavefront sums {b:.0f} ({100 * (1 - b / a):.1f} % less), mean wavefront {m:.0f}")
