@@ -126,10 +126,13 @@ const char *ascent_strerror(int code);
  * host involvement; the split pipeline (scheme 1 / formulation 1) and the dense-block path (scheme 2, a few NLPs
  * on long grids) synchronise the stream once per burst of interior-point rounds, because the host steers the
  * rounds, and return with the last kernels enqueued.
- * Concurrency: the library keeps ONE workspace per device.  Calls on the same device are serialised on the
- * host by a mutex, and a call whose predecessor on that device is still executing (asynchronous device-
- * pointer calls on different streams) makes its stream wait for the predecessor's last kernel first
- * (hipStreamWaitEvent), so two solves never share the workspace in flight. */
+ * Concurrency: host-side, calls on one device are serialised by a mutex.  Device-side, the library keeps a workspace per
+ * caller stream (up to three non-default streams per device; the default stream, the parity surfaces and any further
+ * stream share workspace 0): solves enqueued on different streams with device pointers overlap on the device -- the
+ * wavefronts of one fill the SIMDs the stragglers of the other leave idle (bench.py: pipelined_two_streams) -- while
+ * a call whose predecessor in the SAME workspace is still executing makes its stream wait for that predecessor's last
+ * kernel first (hipStreamWaitEvent), so two solves never share a workspace in flight.  ascent_last_kernel_ms reports
+ * the most recently enqueued solve of the device. */
 int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts *o,
                        const double *guess_or_null, double *traj_out, double *tf_out,
                        int32_t *status_out, int32_t *iters_out, double *sol_blob_out_or_null,

@@ -980,8 +980,24 @@ struct DeviceWs {
   size_t h_p_n = 0, h_guess_n = 0, h_traj_n = 0, h_tf_n = 0, h_blob_n = 0, h_status_n = 0, h_iters_n = 0;
 };
 constexpr int MAX_DEV = 64;
-DeviceWs g_ws[MAX_DEV];
+// Workspaces per device: slot 0 serves the default stream, the parity surfaces and every stream that finds no free slot;
+// up to WS_SLOTS - 1 further caller streams get a workspace of their own, so that solves enqueued on different streams
+// overlap on the device (the wavefronts of one fill the SIMDs the stragglers of the other leave idle).
+constexpr int WS_SLOTS = 4;
+DeviceWs g_wss[MAX_DEV][WS_SLOTS];
+hipStream_t g_ws_stream[MAX_DEV][WS_SLOTS];
+int g_ws_last[MAX_DEV];
 std::mutex g_mu[MAX_DEV];
+#define g_ws_slot0(dev_) g_wss[dev_][0]
+
+static int slot_for(int dev, hipStream_t s) {       // (under g_mu[dev])
+  if (!s) return 0;
+  for (int i = 1; i < WS_SLOTS; i++)
+    if (g_ws_stream[dev][i] == s) return i;
+  for (int i = 1; i < WS_SLOTS; i++)
+    if (!g_ws_stream[dev][i]) { g_ws_stream[dev][i] = s; return i; }
+  return 0;
+}
 
 // Which solver runs a batch: the split pipeline (ascent_pipeline.hip: node-parallel evaluation + thin
 // serial sweeps, best while the batch alone cannot fill the chip) or the fused one-lane-per-NLP kernel
@@ -1008,8 +1024,7 @@ size_t ws_bytes(int K, int64_t batch, int lpt) {
   return tiles * tile_doubles(K) * sizeof(double);
 }
 
-int ensure_ws(int dev, size_t bytes) {
-  DeviceWs &w = g_ws[dev];
+int ensure_ws(DeviceWs &w, size_t bytes) {
   if (!w.ev0) {
     HIPCHK(hipEventCreate(&w.ev0));
     HIPCHK(hipEventCreate(&w.ev1));
@@ -1094,7 +1109,7 @@ const char *ascent_strerror(int code) {
 double ascent_last_kernel_ms(int device_id) {
   if (device_id < 0 || device_id >= MAX_DEV) return -1.0;
   std::lock_guard<std::mutex> lock(g_mu[device_id]);
-  DeviceWs &w = g_ws[device_id];
+  DeviceWs &w = g_wss[device_id][g_ws_last[device_id]];
   if (!w.launched) return -1.0;
   if (hipSetDevice(device_id) != hipSuccess) return -1.0;
   if (hipEventSynchronize(w.ev1) != hipSuccess) return -1.0;
@@ -1138,9 +1153,11 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
       }
     }
   }
-  rc = ensure_ws(device_id, persist ? persist_ws_bytes_nested(levels, nlev, (long)batch) : dense ? (pcr ? dense_pcr_ws_bytes(K, (long)batch) : dense_ws_bytes(K, (long)batch)) : split ? pipeline_ws_bytes(K, (long)batch) : ws_bytes(K, batch, lpt));
+  const int slot = slot_for(device_id, stream);
+  DeviceWs &w = g_wss[device_id][slot];
+  g_ws_last[device_id] = slot;
+  rc = ensure_ws(w, persist ? persist_ws_bytes_nested(levels, nlev, (long)batch) : dense ? (pcr ? dense_pcr_ws_bytes(K, (long)batch) : dense_ws_bytes(K, (long)batch)) : split ? pipeline_ws_bytes(K, (long)batch) : ws_bytes(K, batch, lpt));
   if (rc) return rc;
-  DeviceWs &w = g_ws[device_id];
   const double mu0 = o->mu_init > 0 ? o->mu_init : (o->warm_start ? 1e-4 : 0.1);
 
   const ascent_params *dp = p;
@@ -1282,11 +1299,11 @@ int ascent_eval_nodes_path(const ascent_params *p, int64_t batch, const ascent_o
                        bit.d, bd.d, bj.d, bh.d);
     HIPCHK(hipGetLastError());
   } else {
-    rc = ensure_ws(device_id, pipeline_ws_bytes(K, (long)batch));
+    rc = ensure_ws(g_ws_slot0(device_id), pipeline_ws_bytes(K, (long)batch));
     if (rc) return rc;
     HIPCHK(bz.alloc(batch));                       // mu, delta_w: not used by the node evaluation
     HIPCHK(hipMemset(bz.d, 0, batch * sizeof(double)));
-    rc = pipeline_probe(bp.d, (long)batch, K, (int)o->scheme, (int)o->formulation, g_ws[device_id].ws, bit.d, bz.d, bz.d,
+    rc = pipeline_probe(bp.d, (long)batch, K, (int)o->scheme, (int)o->formulation, g_ws_slot0(device_id).ws, bit.d, bz.d, bz.d,
                         path == ASCENT_PATH_SPLIT_WIDE, false, nullptr, nullptr, bd.d, bj.d, bh.d, 0, g_err, sizeof g_err);
     if (rc) return rc;
   }
@@ -1319,7 +1336,7 @@ int ascent_kkt_step_path(const ascent_params *p, int64_t batch, const ascent_opt
   const size_t rows = 21 * (size_t)K + NSC;
   const int lpt = lanes_per_tile(batch);
   const bool pcr_probe = path == ASCENT_PATH_DENSE && use_pcr_newton(batch);
-  rc = ensure_ws(device_id, path == ASCENT_PATH_DENSE ? (pcr_probe ? dense_pcr_ws_bytes(K, (long)batch) : dense_ws_bytes(K, (long)batch))
+  rc = ensure_ws(g_ws_slot0(device_id), path == ASCENT_PATH_DENSE ? (pcr_probe ? dense_pcr_ws_bytes(K, (long)batch) : dense_ws_bytes(K, (long)batch))
                             : path == ASCENT_PATH_PERSIST ? persist_ws_bytes(K, (long)batch) : path == ASCENT_PATH_FUSED ? ws_bytes(K, batch, lpt) : pipeline_ws_bytes(K, (long)batch));
   if (rc) return rc;
   DevBuf<ascent_params> bp;
@@ -1337,18 +1354,18 @@ int ascent_kkt_step_path(const ascent_params *p, int64_t batch, const ascent_opt
     HIPCHK(hipGetLastError());
   }
   if (path == ASCENT_PATH_DENSE) {
-    rc = dense_probe(bp.d, (long)batch, K, (int)o->scheme, 0, g_ws[device_id].ws, bit.d, bmu.d, bdw.d, true, bst.d, bin.d, nullptr,
+    rc = dense_probe(bp.d, (long)batch, K, (int)o->scheme, 0, g_ws_slot0(device_id).ws, bit.d, bmu.d, bdw.d, true, bst.d, bin.d, nullptr,
                      0, g_err, sizeof g_err, pcr_probe ? 1 : 0);
     if (rc) return rc;
   } else if (path == ASCENT_PATH_PERSIST) {
-    rc = persist_probe(bp.d, (long)batch, K, g_ws[device_id].ws, bit.d, bmu.d, bdw.d, bst.d, bin.d, 0, g_err, sizeof g_err);
+    rc = persist_probe(bp.d, (long)batch, K, g_ws_slot0(device_id).ws, bit.d, bmu.d, bdw.d, bst.d, bin.d, 0, g_err, sizeof g_err);
     if (rc) return rc;
   } else if (path == ASCENT_PATH_FUSED) {
     hipLaunchKernelGGL(k_kkt_step, dim3((unsigned)((batch + lpt - 1) / lpt)), dim3(WAVE), 0, 0, bp.d, (long)batch, lpt, K,
-                       g_ws[device_id].ws, bit.d, bmu.d, bdw.d, bst.d, bin.d);
+                       g_ws_slot0(device_id).ws, bit.d, bmu.d, bdw.d, bst.d, bin.d);
     HIPCHK(hipGetLastError());
   } else {
-    rc = pipeline_probe(bp.d, (long)batch, K, (int)o->scheme, (int)o->formulation, g_ws[device_id].ws, bit.d, bmu.d, bdw.d,
+    rc = pipeline_probe(bp.d, (long)batch, K, (int)o->scheme, (int)o->formulation, g_ws_slot0(device_id).ws, bit.d, bmu.d, bdw.d,
                         path == ASCENT_PATH_SPLIT_WIDE, true, bst.d, bin.d, nullptr, nullptr, nullptr, 0, g_err, sizeof g_err);
     if (rc) return rc;
   }
@@ -1368,7 +1385,7 @@ int ascent_dense_records(const ascent_params *p, int64_t batch, const ascent_opt
   HIPCHK(hipSetDevice(device_id));
   const int K = o->n_nodes - 1;
   const size_t rows = 21 * (size_t)K + NSC, nrec = (size_t)batch * K * 6 * 64;
-  rc = ensure_ws(device_id, dense_ws_bytes(K, (long)batch));
+  rc = ensure_ws(g_ws_slot0(device_id), dense_ws_bytes(K, (long)batch));
   if (rc) return rc;
   DevBuf<ascent_params> bp;
   DevBuf<double> bit, bz, br;
@@ -1380,7 +1397,7 @@ int ascent_dense_records(const ascent_params *p, int64_t batch, const ascent_opt
     hipLaunchKernelGGL(k_terminal_params, dim3((unsigned)((batch + WAVE - 1) / WAVE)), dim3(WAVE), 0, 0, bp.d, bp.d, (long)batch);
     HIPCHK(hipGetLastError());
   }
-  rc = dense_probe(bp.d, (long)batch, K, (int)o->scheme, 0, g_ws[device_id].ws, bit.d, bz.d, bz.d, false, nullptr, nullptr, br.d, 0,
+  rc = dense_probe(bp.d, (long)batch, K, (int)o->scheme, 0, g_ws_slot0(device_id).ws, bit.d, bz.d, bz.d, false, nullptr, nullptr, br.d, 0,
                    g_err, sizeof g_err);
   if (rc) return rc;
   HIPCHK(hipMemcpy(records, br.d, nrec * sizeof(double), hipMemcpyDeviceToHost));
@@ -1437,9 +1454,9 @@ int ascent_kkt_solve(int64_t batch, int32_t n, int32_t bs, int32_t nb, const dou
   if (device_id < 0 || device_id >= ndev || device_id >= MAX_DEV) { snprintf(g_err, sizeof g_err, "device %d of %d", device_id, ndev); return ASCENT_E_NODEVICE; }
   std::lock_guard<std::mutex> lock(g_mu[device_id]);
   HIPCHK(hipSetDevice(device_id));
-  int rc = ensure_ws(device_id, blocktri_ws_bytes(n, (long)batch, algo));
+  int rc = ensure_ws(g_ws_slot0(device_id), blocktri_ws_bytes(n, (long)batch, algo));
   if (rc) return rc;
-  DeviceWs &w = g_ws[device_id];
+  DeviceWs &w = g_ws_slot0(device_id);
   const size_t nblk = (size_t)batch * n * bs * bs, nbor = (size_t)batch * n * bs * (nb ? nb : 1), nrow = (size_t)n * bs + nb;
   const size_t ny = (size_t)batch * n * bs * (1 + nb);
   DevBuf<double> bd, bl, bu, bb, br, by;

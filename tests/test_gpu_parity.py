@@ -518,3 +518,38 @@ def test_high_resolution_grid_matches_oracle(coracle):
         assert abs(r.final_time()[0] - t_expect) < 0.01
         for f in (0, 1, 2, 3, 6, 9):
             assert np.abs(np.moveaxis(r.traj[f], 1, 0) - ref["traj"][:, f]).max() <= 1e-6 * max(1.0, np.abs(ref["traj"][:, f]).max())
+
+
+_TWO_STREAMS = r"""
+import sys, numpy as np, torch
+torch.cuda.set_device(0)                      # torch's HIP runtime first, as in bench.py (the library then binds to the same one)
+sys.path.insert(0, %r)
+import lunar_module_ascent_trajectory_optimiser_amd as A
+dev = torch.device("cuda", 0)
+Pa = torch.from_numpy(A.sweep_isp_drymass(16, 16)).to(dev)
+Pb = torch.from_numpy(np.ascontiguousarray(A.sweep_config4()[::1031][:200])).to(dev)
+ref_a = {k: v.clone() for k, v in A.solve_batch_torch(Pa, 200, tol=1e-9, sync=True).items()}
+ref_b = {k: v.clone() for k, v in A.solve_batch_torch(Pb, 120, tol=1e-9, sync=True).items()}
+sa, sb = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+oa, ob = {}, {}
+for _ in range(4):
+    with torch.cuda.stream(sa):
+        A.solve_batch_torch(Pa, 200, tol=1e-9, out=oa)
+    with torch.cuda.stream(sb):
+        A.solve_batch_torch(Pb, 120, tol=1e-9, out=ob)
+torch.cuda.synchronize(dev)
+for o, r in ((oa, ref_a), (ob, ref_b)):
+    assert bool((o["status"] == 0).all()) and torch.equal(o["iters"], r["iters"])
+    assert torch.equal(o["tf"], r["tf"]) and torch.equal(o["traj"], r["traj"])
+print("two-streams-ok")
+"""
+
+
+def test_solves_on_two_streams_overlap_safely():
+    """One workspace per caller stream (include/ascent.h, Concurrency): solves enqueued alternately on two streams, different
+    batches and grids in flight at once, give bit-identical results to the same solves run one after another.  (In a process of
+    its own: torch has to bring up its HIP runtime before the library binds to one.)"""
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", _TWO_STREAMS % root], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "two-streams-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
