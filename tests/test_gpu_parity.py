@@ -553,3 +553,15 @@ def test_solves_on_two_streams_overlap_safely():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     r = subprocess.run([sys.executable, "-c", _TWO_STREAMS % root], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "two-streams-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_unusual_grid_sizes_match_oracle(coracle):
+    """Tiny grids, grids around the 16-interval chunk boundaries of the persistent kernel, grids with several nested levels:
+    same status, same iteration counts and t_f to rounding as the C oracle on every problem."""
+    S = A.sweep_isp_drymass(3, 3)
+    for nt in (3, 4, 5, 8, 14, 16, 17, 18, 32, 33, 34, 49, 65, 199, 201, 257, 640):
+        r = A.solve_batch(S, nt, tol=1e-9, max_iter=500)
+        o = coracle.solve_batch(S, nt, 500, 1e-9)
+        assert np.array_equal(r.status, o["status"]) and np.all(r.status == 0), nt
+        assert np.array_equal(r.iters, o["iters"]), nt
+        assert np.abs(r.tf - o["tf"]).max() <= 1e-12, nt
