@@ -318,6 +318,10 @@ def main():
             oc["config1_single_nlp"] = {"ms_per_solve": ms1, "converged": int((r1.status == 0).sum()), "iterations": int(r1.iters[0]),
                                         "final_time_s": float(r1.final_time()[0]), "path": A.default_path(1, NT),
                                         "what": "the reference's own problem (Apollo 11, N=200, backward Euler), cold start"}
+            r1t, ms1t = timed(lambda: A.solve_batch(A.AscentParams(), NT, tol=args.tol, scheme=1))
+            oc["config1_single_nlp_trapezoid"] = {"ms_per_solve": ms1t, "converged": int((r1t.status == 0).sum()), "iterations": int(r1t.iters[0]),
+                                                  "final_time_s": float(r1t.final_time()[0]), "path": A.default_path(1, NT, scheme=1),
+                                                  "what": "the same problem with scheme 1 (BASELINE.json configs[1] says 'trapezoidal'; the reference's NODES=2 is backward Euler, SURVEY.md 8a1)"}
             S4 = np.ascontiguousarray(A.sweep_config4()[:32768])
             r4, ms4 = timed(lambda: A.solve_batch(S4, NT, tol=args.tol, want_traj=False))
             oc["config4_shard0"] = {"value": float((r4.status == 0).sum()) / (ms4 * 1e-3), "unit": "NLPs/s", "ms_per_solve": ms4,
