@@ -5,17 +5,20 @@
 // of every collocation node (/root/reference/Launch_Optimiser.py:114-136) are materialised in HBM by one kernel and read
 // back by four others (55 rows per node and iteration, 8.8x the algorithmic bytes at batch 4096), and the host steers
 // the rounds.  Here a wavefront keeps its four NLPs from the initial point to convergence:
-//   * the serial sweeps are the 16-lanes-per-NLP sweeps of the split pipeline (lanes 0-6 one column each of the 7x7
-//     value function, lanes 7-9 the three right-hand sides; DPP row broadcasts, LDS transposes);
-//   * the node-parallel work -- trial point, defects, Jacobian / Hessian blocks, merit and KKT-error pieces, bound-multiplier
-//     steps, adjoint right-hand sides -- is done by the SAME wavefront, 64 lanes = 4 NLPs x 16 consecutive nodes, one
-//     16-node chunk at a time, and handed to the sweep through LDS: the blocks of a chunk are produced into LDS, consumed
-//     by the 16 serial steps of that chunk and overwritten by the next chunk.  They never reach HBM; phases that need them
-//     again (forward, adjoint) evaluate them again (FP64 issue is what a lone wavefront per SIMD has to spare);
+//   * the factorisation sweep is the 16-lanes-per-NLP sweep of the split pipeline (lanes 0-6 one column each of the 7x7
+//     value function, lanes 7-9 the three right-hand sides; DPP row broadcasts, an LDS transpose per step); the forward and
+//     adjoint sweeps are affine recursions whose node-local matrices the node-parallel phase forms: one row of a
+//     matrix-vector product per lane and step;
+//   * the node-parallel work -- trial point, defects, Jacobian / Hessian blocks, recursion matrices, merit and KKT-error
+//     pieces, bound-multiplier steps, adjoint right-hand sides -- is done by the SAME wavefront, 64 lanes = 4 NLPs x 16
+//     consecutive nodes, one 16-node chunk at a time, and handed to the sweep through LDS: the blocks of a chunk are
+//     produced into LDS, consumed by the 16 serial steps of that chunk and overwritten by the next chunk.  They never reach
+//     HBM; phases that need them again (forward, adjoint) evaluate them again;
 //   * HBM holds, per NLP and node, the two iterate buffers, the step and the ten feedback gains of the factorisation
 //     ([NLP][row][node], node contiguous: a chunk row of an NLP is one 128-byte line);
 //   * line-search rejections, inertia corrections and the barrier schedule are per-NLP state in LDS; wavefronts do not
-//     wait for one another and the host is not involved until the level is finished.
+//     wait for one another and the host is not involved until the level is finished; the grid levels of the nested
+//     iteration hand over inside this layout (p_transfer).
 // Backward Euler (the reference's NODES=2), current formulation; the other schemes keep the split pipeline.
 #include <hip/hip_runtime.h>
 

@@ -924,10 +924,10 @@ bool use_dense_path(const ascent_opts *o, int64_t batch) {
   if (o->scheme == 2 || o->solver_path == ASCENT_PATH_DENSE) return true;
   const char *e = getenv("ASCENT_PIPELINE");
   if (e) return !strcmp(e, "dense") && o->formulation == 0;
-  // A handful of NLPs cannot fill the hand-tuned kernels (one wavefront per four NLPs, serial over the nodes: 3.3 ms at
-  // N=200, 9 ms at N=600, 31-35 ms at N=2000 for up to 16 NLPs); the dense-block path with its Newton systems solved by
+  // A handful of NLPs cannot fill the hand-tuned kernels (one wavefront per four NLPs, serial over the nodes: 2.8 ms at
+  // N=200, 7.3 ms at N=600, 25-31 ms at N=2000 for up to 8 NLPs); the dense-block path with its Newton systems solved by
   // cyclic reduction over the nodes spreads ONE NLP over hundreds of wavefronts and costs ~1 us per node and NLP on top of
-  // a start-up that grows with log N: 3.4 ms (N=200), 4.3 ms (N=600), 8.6 ms (N=2000) for a single NLP; 4.4 / 8.6 / 24 ms
+  // a start-up that grows with log N: 3.4 ms (N=200), 4.4 ms (N=600), 8.6 ms (N=2000) for a single NLP; 4.4 / 8.6 / 24 ms
   // for eight (scripts/small_batch_paths.py).  Backward Euler: taken on grids of >= 400 intervals while batch <=
   // min(8, intervals/75); the trapezoid (whose hand-tuned path is the slower split pipeline) up to 8 NLPs on any grid.
   // ASCENT_SMALL_BATCH=off keeps the hand-tuned path.
