@@ -439,6 +439,7 @@ static double barrier(const oder *d, const iter_t *it, double mu) {
   return th - mu * sl;
 }
 
+static double g_err_rd, g_err_cc, g_err_comp, g_err_sd;     /* the pieces of the last kkt_error (trace only) */
 /* optimality error E_mu (Waechter & Biegler eq. 5) */
 static double kkt_error(const oder *d, work_t *w, const iter_t *it, double mu) {
   int K = w->K; double hT = w->h * d->T, th = it->sc[S_TH], dt = hT * th;
@@ -479,6 +480,7 @@ static double kkt_error(const oder *d, work_t *w, const iter_t *it, double mu) {
   l1 += fabs(it->sc[S_NU3]) + fabs(it->sc[S_NU1]) + fabs(it->sc[S_NU2]);
   zsum += it->sc[S_ZLT] + it->sc[S_ZUT] + it->sc[S_ZS1] + it->sc[S_ZS2];
   double sd = fmax(100.0, (l1 + zsum) / (double)(7 * K + 3 + 6 * K + 4)) / 100.0;
+  g_err_rd = rd; g_err_cc = cc; g_err_comp = comp; g_err_sd = sd;
   return fmax(fmax(rd / sd, cc), comp / sd);
 }
 
@@ -546,6 +548,7 @@ static int solve_one(const oparams *prm, int nt, int max_iter, double tol, int w
   int status = ST_MAXITER, iters = 0, nreg = 0;
   for (int iter = 0; iter < max_iter; iter++) {
     double e0 = kkt_error(&d, w, &it, 0.0);
+    const double t_rd = g_err_rd, t_cc = g_err_cc, t_comp = g_err_comp, t_sd = g_err_sd;
     if (e0 <= tol) { status = ST_CONVERGED; break; }
     while (mu > tol / 10.0 && kkt_error(&d, w, &it, mu) <= g_keps * mu) {
       mu = fmax(tol / 10.0, fmin(g_kmu * mu, pow(mu, g_thmu)));
@@ -603,8 +606,8 @@ static int solve_one(const oparams *prm, int nt, int max_iter, double tol, int w
       alpha *= 0.5;
     }
     if (!ok) { status = ST_LINESEARCH; break; }
-    if (g_trace) fprintf(stderr, "[oracle] K=%d iter %2d mu %.1e E0 %.2e Emu %.2e alpha %.3g (apr %.3g) adu %.3g dw %.1e nu_pen %.2g c1 %.2e\n", K, iter, mu, e0,
-                         kkt_error(&d, w, &it, mu), alpha, apr, adu, dw, nu_pen, c1);
+    if (g_trace) fprintf(stderr, "[oracle] K=%d iter %2d mu %.1e E0 %.2e (dual %.1e primal %.1e compl %.1e s_d %.2g) Emu %.2e alpha %.3g (apr %.3g) adu %.3g dw %.1e nu_pen %.2g c1 %.2e\n", K, iter, mu, e0,
+                         t_rd, t_cc, t_comp, t_sd, kkt_error(&d, w, &it, mu), alpha, apr, adu, dw, nu_pen, c1);
     for (int i = 0; i < 8 * K; i++) blob[i] += alpha * w->step[i];
     for (int i = 0; i < 7 * K; i++) it.lam[i] += alpha * st.lam[i];
     for (int i = 0; i < 6 * K; i++) it.zb[i] += adu * st.zb[i];
