@@ -565,3 +565,17 @@ def test_unusual_grid_sizes_match_oracle(coracle):
         assert np.array_equal(r.status, o["status"]) and np.all(r.status == 0), nt
         assert np.array_equal(r.iters, o["iters"]), nt
         assert np.abs(r.tf - o["tf"]).max() <= 1e-12, nt
+
+
+def test_config4_whole_box_on_one_gpu(coracle):
+    """BASELINE.json configs[3] in full -- 262 144 NLPs (64 x 64 x 8 x 8: Isp, dry mass, apoapsis, angular-acceleration cap) -- as
+    ONE batch on one GPU: every problem converges; a shard solved on its own gives bit-identical results (what each of
+    eight GPUs would compute); spread samples agree with the oracle with equal iteration counts."""
+    full = A.sweep_config4()
+    r = A.solve_batch(full, NT, tol=1e-9, want_traj=False)
+    assert len(full) == 262144 and np.all(r.status == 0) and r.iters.max() <= 30
+    sh = A.solve_batch(full[5 * 32768:6 * 32768], NT, tol=1e-9, want_traj=False)
+    assert np.array_equal(sh.tf, r.tf[5 * 32768:6 * 32768]) and np.array_equal(sh.iters, r.iters[5 * 32768:6 * 32768])
+    idx = np.linspace(0, len(full) - 1, 48).astype(int)
+    ref = coracle.solve_batch(full[idx], NT, 300, 1e-9)
+    assert np.array_equal(r.iters[idx], ref["iters"]) and np.abs(r.tf[idx] - ref["tf"]).max() <= 1e-12
