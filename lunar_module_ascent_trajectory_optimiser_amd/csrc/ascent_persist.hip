@@ -19,7 +19,7 @@
 //   * line-search rejections, inertia corrections and the barrier schedule are per-NLP state in LDS; wavefronts do not
 //     wait for one another and the host is not involved until the level is finished; the grid levels of the nested
 //     iteration hand over inside this layout (p_transfer).
-// Backward Euler (the reference's NODES=2), current formulation; the other schemes keep the split pipeline.
+// Backward Euler (the reference's NODES=2) and the trapezoid (p_solve<1>), current formulation.
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -379,6 +379,7 @@ struct TrialCtx {       // what the trial point of an NLP needs besides the node
 
 // The trial point x + alpha dx at node k (iterate n, step dn), stored into the other iterate buffer, and its pieces of the
 // l1 merit function and of the KKT error (Launch_Optimiser.py:114-136 evaluated once, with first derivatives).
+template <int SCHEME>
 ASC_DEV void trial_node(const Der &d, int K, int Kp, int k, const NodeIn &n, const NodeIn &dn, const TrialCtx &t, bool live,
                         double *in, Part &P) {
   const double alpha = t.alpha;
@@ -402,14 +403,26 @@ ASC_DEV void trial_node(const Der &d, int K, int Kp, int k, const NodeIn &n, con
     ASC_UNROLL
     for (int b = 0; b < 6; b++) in[(O_ZB + b) * Kp + k] = zb[b];
   }
-  double G[8], F[7], fl[7], ax, ay;
+  // (scheme 1, the trapezoid with the control held over the step: defect z_k - z_{k-1} - dt/2 [f(z_k,u_k) + f(z_{k-1},u_k)]; node k then
+  //  carries the multipliers of steps k and k+1 in its stationarity row, each with half the step)
+  const double cs = SCHEME == 1 ? 0.5 * t.dt : t.dt;
+  double G[8], F[7], fl[7], lt[7], ax, ay;
   accel<1>(d, z[IX], z[IY], z[IA], z[IM], 0.0, 0.0, ax, ay, G, nullptr);
   rhs_f(d, z, u, ax, ay, F);
-  fzt_lambda(G, l, fl);
+  if (SCHEME == 1) {
+    double Fb[7], axp, ayp;
+    accel<0>(d, zp[IX], zp[IY], zp[IA], zp[IM], 0.0, 0.0, axp, ayp, nullptr, nullptr);
+    rhs_f(d, zp, u, axp, ayp, Fb);
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) F[i] = 0.5 * (F[i] + Fb[i]);
+  }
+  ASC_UNROLL
+  for (int i = 0; i < 7; i++) lt[i] = SCHEME == 1 ? l[i] + ln[i] : l[i];
+  fzt_lambda(G, lt, fl);
   double r[7];
   ASC_UNROLL
   for (int i = 0; i < 7; i++) {
-    r[i] = l[i] - t.dt * fl[i] - ln[i];
+    r[i] = l[i] - cs * fl[i] - ln[i];
     const double cc = z[i] - zp[i] - t.dt * F[i];
     P.c1 += fabs(cc);
     P.cinf = fmax(P.cinf, fabs(cc));
@@ -450,6 +463,7 @@ ASC_DEV void trial_node(const Der &d, int K, int Kp, int k, const NodeIn &n, con
 #define PROF_END do { } while (0)
 #endif
 
+template <int SCHEME>
 __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, long batch, PGeo g, double *ws, int max_iter, double tol) {
   __shared__ double stage[S_ROWS * LDW];
   __shared__ double outb[OUT_ROWS * LDW];
@@ -506,7 +520,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             load_node(ic, Kp, K, k, n);
             if (first) dn = NodeIn{};             // (no step yet; the step rows are not initialised)
             else load_node(stp, Kp, K, k, dn);
-            trial_node(d, K, Kp, k, n, dn, t, live, in, P);
+            trial_node<SCHEME>(d, K, Kp, k, n, dn, t, live, in, P);
           }
         }
         P.reduce16();
@@ -574,7 +588,8 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
       const Scal s = lds_scal(sc, X_S);
       const double mu = sc[X_MU], dw = sc[X_DW];
       const double *it = w + (size_t)((int)sc[X_CUR] * NIT) * Kp;
-      const double dt = hT * s.th, be = dt * d.alpha, ith = rcp(s.th), cs = dt, bu = be;
+      const double dt = hT * s.th, be = dt * d.alpha, ith = rcp(s.th), cs = SCHEME == 1 ? 0.5 * dt : dt, bu = be;
+      const double hTc = SCHEME == 1 ? 0.5 * hT : hT;
       // what this lane gathers from a step's blocks for row i of its vector (factor phase), as in q_factor_wide
       int grow[7];
       double gsgn[7];
@@ -638,11 +653,20 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
           if (k < K && act) {
             NodeIn n;
             load_node(it, Kp, K, k, n);
-            double G[8], E[4], H[10], F[7], fl[7], ax, ay;
-            accel<2>(d, n.z[IX], n.z[IY], n.z[IA], n.z[IM], -cs * n.l[IVX], -cs * n.l[IVY], ax, ay, G, H);
+            double G[8], E[4], H[10], F[7], fl[7], lt[7], ax, ay;
+            ASC_UNROLL
+            for (int i = 0; i < 7; i++) lt[i] = SCHEME == 1 ? n.l[i] + n.ln[i] : n.l[i];
+            accel<2>(d, n.z[IX], n.z[IY], n.z[IA], n.z[IM], -cs * lt[IVX], -cs * lt[IVY], ax, ay, G, H);
             rhs_f(d, n.z, n.u, ax, ay, F);
+            if (SCHEME == 1) {       // second evaluation point of the step: f(z_{k-1}, u_k)
+              double Fb[7], axp, ayp;
+              accel<0>(d, n.zp[IX], n.zp[IY], n.zp[IA], n.zp[IM], 0.0, 0.0, axp, ayp, nullptr, nullptr);
+              rhs_f(d, n.zp, n.u, axp, ayp, Fb);
+              ASC_UNROLL
+              for (int i = 0; i < 7; i++) F[i] = 0.5 * (F[i] + Fb[i]);
+            }
             implicit_block(G, cs, E);
-            fzt_lambda(G, n.l, fl);
+            fzt_lambda(G, lt, fl);
             const double dist[6] = {n.z[IA], d.aub - n.z[IA], n.z[IM], 1.0 - n.z[IM], n.u + 1.0, 1.0 - n.u};
             double id[6];
             ASC_UNROLL
@@ -660,7 +684,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
               stage[(S_F + i) * LDW + col] = hT * F[i];            // (pre-scaled: the sweep uses hT F only)
               stage[(S_C + i) * LDW + col] = n.z[i] - n.zp[i] - dt * F[i];
               stage[(S_RZ + i) * LDW + col] = n.l[i] - cs * fl[i] - n.ln[i];
-              stage[(S_GT + i) * LDW + col] = -hT * fl[i];
+              stage[(S_GT + i) * LDW + col] = -hTc * fl[i];
             }
             const double scr[5] = {n.zb[4] * id[4] + n.zb[5] * id[5], -be * n.l[IW], id[1] - id[0], id[3] - id[2], id[5] - id[4]};
             ASC_UNROLL
@@ -688,6 +712,24 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
                                   bcast16<4>(gB), bcast16<5>(gB), bcast16<6>(gB)};
             const double rc1[7] = {bcast16<7>(gB), bcast16<8>(gB), bcast16<9>(gB), bcast16<10>(gB), bcast16<11>(gB),
                                    bcast16<12>(gB), bcast16<13>(gB)};
+            if (SCHEME == 1 && k < K - 1) {   // pull the value function of step k+1 back through Abar = I + cs F_z(z_k): Abar' on every
+              double t[7];                    // column and right-hand side, transpose, Abar' on the columns again
+              fzt_lambda(G, a, t);
+              ASC_UNROLL
+              for (int i = 0; i < 7; i++) a[i] += cs * t[i];
+              if (colr) {
+                ASC_UNROLL
+                for (int i = 0; i < 7; i++) lds_t[grp][role][i] = a[i];
+                wsync();
+                double r[7];
+                ASC_UNROLL
+                for (int l2 = 0; l2 < 7; l2++) r[l2] = lds_t[grp][l2][role];
+                fzt_lambda(G, r, t);
+                ASC_UNROLL
+                for (int i = 0; i < 7; i++) a[i] = r[i] + cs * t[i];
+              }
+              wsync();                        // lds_t is written again below
+            }
             ASC_UNROLL
             for (int i = 0; i < 7; i++) a[i] += gsgn[i] * gq[i];
             a[IA] += bsc * bza;
@@ -812,7 +854,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
       const double sig1 = sc[X_SIG1], sig2 = sc[X_SIG2], rs1 = sc[X_RS1], rs2 = sc[X_RS2];
       const double *it = w + (size_t)((int)sc[X_CUR] * NIT) * Kp;
       double *stp = w + (size_t)R_ST * Kp;
-      const double dt = hT * s.th, be = dt * d.alpha, cs = dt;
+      const double dt = hT * s.th, be = dt * d.alpha, cs = SCHEME == 1 ? 0.5 * dt : dt, hTc = SCHEME == 1 ? 0.5 * hT : hT;
       const double tau = fmax(0.99, 1.0 - mu);
       // ---- forward -----------------------------------------------------------------------------------------------
       {
@@ -831,7 +873,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
           const int kn = c * CH + role;
           const bool on = kn < K && act;
           double a_ = 0.5, m_ = 0.5, u_ = 0.0, zb[6] = {1, 1, 1, 1, 1, 1};
-          double G[8], E[4], x0[7], ka[7], du00 = 0.0;
+          double G[8], Gp[8], E[4], x0[7], ka[7], du00 = 0.0;        // (Gp: scheme 1 only, the Jacobian block of node k-1)
           ASC_UNROLL
           for (int i = 0; i < 7; i++) { x0[i] = 0.0; ka[i] = 0.0; }
           if (on) {
@@ -847,6 +889,13 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             du00 = w[(size_t)R_K0 * Kp + kn] + w[(size_t)(R_K0 + 1) * Kp + kn] * dth + w[(size_t)(R_K0 + 2) * Kp + kn] * dnu3;
             accel<1>(d, z[IX], z[IY], z[IA], z[IM], 0.0, 0.0, ax, ay, G, nullptr);
             rhs_f(d, z, u_, ax, ay, F);
+            if (SCHEME == 1) {       // second evaluation point f(z_{k-1}, u_k); its Jacobian is the Abar_k = I + cs F_z(z_{k-1}) of the step
+              double Fb[7], axp, ayp;
+              accel<1>(d, zp[IX], zp[IY], zp[IA], zp[IM], 0.0, 0.0, axp, ayp, Gp, nullptr);
+              rhs_f(d, zp, u_, axp, ayp, Fb);
+              ASC_UNROLL
+              for (int i = 0; i < 7; i++) F[i] = 0.5 * (F[i] + Fb[i]);
+            }
             implicit_block(G, cs, E);
             ASC_UNROLL
             for (int i = 0; i < 7; i++) {
@@ -870,6 +919,21 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             // row i of M = (row i of A^-1) - be aW[i] ka',  v[i] = (row i of A^-1) . x0 + be aW[i] du00' + A^-1[i][m] dz_m,k-1,  aW = A^-1 e_w
             auto emit = [&](int i, const double *r, double aw) {
               const double bw = be * aw;
+              if (SCHEME == 1) {       // dz_k = M Abar_k dz_{k-1} + v: the row times Abar (= row + cs F_z' row), its mass entry folded into v
+                double m7[7], t[7];
+                ASC_UNROLL
+                for (int j = 0; j < 7; j++) m7[j] = r[j] - bw * ka[j];
+                fzt_lambda(Gp, m7, t);
+                ASC_UNROLL
+                for (int j = 0; j < 7; j++) m7[j] += cs * t[j];
+                double v = bw * du00 + m7[IM] * dzm_p;
+                ASC_UNROLL
+                for (int j = 0; j < 7; j++) v += r[j] * x0[j];
+                ASC_UNROLL
+                for (int j = 0; j < 6; j++) stage[(7 * i + j) * LDW + col] = m7[j];
+                stage[(7 * i + 6) * LDW + col] = v;
+                return;
+              }
               double v = bw * du00p + r[IM] * dzm_p;
               ASC_UNROLL
               for (int j = 0; j < 7; j++) v += r[j] * x0[j];
@@ -894,9 +958,17 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
               for (int j = 0; j < 7; j++) r[j] = j == IW ? 1.0 : 0.0;
               emit(IW, r, 1.0);
             }
-            ASC_UNROLL
-            for (int j = 0; j < 6; j++) stage[(42 + j) * LDW + col] = -ka[j];
-            stage[48 * LDW + col] = du00p;
+            if (SCHEME == 1) {         // du_k = du00 - ka' Abar_k dz_{k-1}
+              double t[7];
+              fzt_lambda(Gp, ka, t);
+              ASC_UNROLL
+              for (int j = 0; j < 6; j++) stage[(42 + j) * LDW + col] = -(ka[j] + cs * t[j]);
+              stage[48 * LDW + col] = du00 - (ka[IM] + cs * t[IM]) * dzm_p;
+            } else {
+              ASC_UNROLL
+              for (int j = 0; j < 6; j++) stage[(42 + j) * LDW + col] = -ka[j];
+              stage[48 * LDW + col] = du00p;
+            }
             outb[6 * LDW + col] = dzm_k;
           }
           wsync();
@@ -1003,18 +1075,27 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             ASC_UNROLL
             for (int b = 0; b < 6; b++) dn.zb[b] = stp[(O_ZB + b) * Kp + kn];
             const double *dz = dn.z;
-            double G[8], E[4], H[10], F[7], fl[7], ax, ay;
-            accel<2>(d, n.z[IX], n.z[IY], n.z[IA], n.z[IM], -cs * n.l[IVX], -cs * n.l[IVY], ax, ay, G, H);
+            double G[8], E[4], H[10], F[7], fl[7], lt[7], ax, ay;
+            ASC_UNROLL
+            for (int i = 0; i < 7; i++) lt[i] = SCHEME == 1 ? n.l[i] + n.ln[i] : n.l[i];
+            accel<2>(d, n.z[IX], n.z[IY], n.z[IA], n.z[IM], -cs * lt[IVX], -cs * lt[IVY], ax, ay, G, H);
             rhs_f(d, n.z, n.u, ax, ay, F);
+            if (SCHEME == 1) {
+              double Fb[7], axp, ayp;
+              accel<0>(d, n.zp[IX], n.zp[IY], n.zp[IA], n.zp[IM], 0.0, 0.0, axp, ayp, nullptr, nullptr);
+              rhs_f(d, n.zp, n.u, axp, ayp, Fb);
+              ASC_UNROLL
+              for (int i = 0; i < 7; i++) F[i] = 0.5 * (F[i] + Fb[i]);
+            }
             implicit_block(G, cs, E);
-            fzt_lambda(G, n.l, fl);
+            fzt_lambda(G, lt, fl);
             const double id0 = rcp(n.z[IA]), id1 = rcp(d.aub - n.z[IA]), id2 = rcp(n.z[IM]), id3 = rcp(1.0 - n.z[IM]);
             H[7] += n.zb[0] * id0 + n.zb[1] * id1;
             H[9] += n.zb[2] * id2 + n.zb[3] * id3;
             double r[7];
             ASC_UNROLL
             for (int i = 0; i < 7; i++) {
-              const double rz = n.l[i] - cs * fl[i] - n.ln[i], gt = -hT * fl[i];
+              const double rz = n.l[i] - cs * fl[i] - n.ln[i], gt = -hTc * fl[i];
               r[i] = -rz - gt * dth - dw * dz[i];
               ccn[i] = n.z[i] - n.zp[i] - dt * F[i];
               ccl += ccn[i] * n.l[i];
@@ -1047,11 +1128,21 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
               ainv_vrows(G, E, cs, rvx, rvy);
               ASC_UNROLL
               for (int i = 0; i < 7; i++) {
-                stage[(6 * i + IVX) * LDW + col] = rvx[i];
-                stage[(6 * i + IVY) * LDW + col] = rvy[i];
-                stage[(6 * i + IX) * LDW + col] = (i == IX ? 1.0 : 0.0) + cs * rvx[i];
-                stage[(6 * i + IY) * LDW + col] = (i == IY ? 1.0 : 0.0) + cs * rvy[i];
-                stage[(6 * i + IA) * LDW + col] = i == IA ? 1.0 : i == IW ? cs : 0.0;
+                double nr[7];             // row i of A^-T
+                nr[IVX] = rvx[i]; nr[IVY] = rvy[i];
+                nr[IX] = (i == IX ? 1.0 : 0.0) + cs * rvx[i];
+                nr[IY] = (i == IY ? 1.0 : 0.0) + cs * rvy[i];
+                nr[IA] = i == IA ? 1.0 : i == IW ? cs : 0.0;
+                nr[IW] = i == IW ? 1.0 : 0.0;
+                nr[IM] = i == IM ? 1.0 : 0.0;
+                if (SCHEME == 1) {      // dl_k = A_k^-T (r_k + Abar_{k+1}' dl_{k+1}),  Abar_{k+1} = I + cs F_z(z_k): the row times Abar'
+                  double t[7];
+                  fz_mul(G, nr, t);
+                  ASC_UNROLL
+                  for (int j = 0; j < 7; j++) nr[j] += cs * t[j];
+                }
+                ASC_UNROLL
+                for (int j = 0; j < 5; j++) stage[(6 * i + j) * LDW + col] = nr[j];
               }
             }
             ASC_UNROLL
@@ -1092,7 +1183,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
               ASC_UNROLL
               for (int i = 0; i < 7; i++) lds_c[grp][i] = dn.l[i];
             }
-            trial_node(d, K, Kp, kn, n, dn, tc, live, in, P);
+            trial_node<SCHEME>(d, K, Kp, kn, n, dn, tc, live, in, P);
           }
           PROF(0);
         }
@@ -1154,7 +1245,7 @@ int persist_run(const ascent_params *dp, long batch, int K, double *ws, const do
                 double mu0, double *dtraj, double *dtf, int *dstatus, int *diters, double *dblob, hipStream_t stream, char *err,
                 size_t errlen) {
   const int levels[1] = {K + 1};
-  return persist_run_nested(dp, batch, levels, 1, ws, dguess, warm, max_iter, tol, tol, mu0, 0.0, 0.0, dtraj, dtf, dstatus, diters, dblob,
+  return persist_run_nested(dp, batch, 0, levels, 1, ws, dguess, warm, max_iter, tol, tol, mu0, 0.0, 0.0, dtraj, dtf, dstatus, diters, dblob,
                             stream, err, errlen);
 }
 
@@ -1167,7 +1258,7 @@ size_t persist_ws_bytes_nested(const int *levels, int nlev, long batch) {
 // All grid levels of the nested iteration (levels[0] = the requested grid, finest first; the coarsest is solved first, cold or
 // from the caller's guess): p_init, then per level p_solve and p_transfer to the next finer grid, p_finish at the end.  Two
 // workspace regions alternate between the levels.
-int persist_run_nested(const ascent_params *dp, long batch, const int *levels, int nlev, double *ws, const double *dguess, int warm,
+int persist_run_nested(const ascent_params *dp, long batch, int scheme, const int *levels, int nlev, double *ws, const double *dguess, int warm,
                        int max_iter, double tol, double tol_coarse, double mu0, double mu_first, double mu_next, double *dtraj,
                        double *dtf, int *dstatus, int *diters, double *dblob, hipStream_t stream, char *err, size_t errlen) {
   double *region[2] = {ws, (double *)((char *)ws + ((persist_ws_bytes(levels[0] - 1, batch) + 255) & ~(size_t)255))};
@@ -1176,8 +1267,8 @@ int persist_run_nested(const ascent_params *dp, long batch, const int *levels, i
   hipLaunchKernelGGL(p_init, dim3((unsigned)((g.Kp + WAVE - 1) / WAVE), (unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g, w, dguess,
                      warm, mu0, (const double *)nullptr, (const double *)nullptr);
   for (int l = nlev - 1; l >= 0; l--) {
-    hipLaunchKernelGGL(p_solve, dim3((unsigned)((batch + NPW - 1) / NPW)), dim3(WAVE), 0, stream, dp, batch, g, w, max_iter,
-                       l == 0 ? tol : tol_coarse);
+    if (scheme == 1) hipLaunchKernelGGL(p_solve<1>, dim3((unsigned)((batch + NPW - 1) / NPW)), dim3(WAVE), 0, stream, dp, batch, g, w, max_iter, l == 0 ? tol : tol_coarse);
+    else hipLaunchKernelGGL(p_solve<0>, dim3((unsigned)((batch + NPW - 1) / NPW)), dim3(WAVE), 0, stream, dp, batch, g, w, max_iter, l == 0 ? tol : tol_coarse);
     if (l > 0) {
       const PGeo gf = geo_of(levels[l - 1] - 1);
       double *wf = region[(l - 1) & 1];
@@ -1194,12 +1285,13 @@ int persist_run_nested(const ascent_params *dp, long batch, const int *levels, i
 
 // One round of p_solve at a caller-supplied iterate (parity surface ascent_kkt_step_path): the iterate as it is, mu and
 // delta_w per problem from the caller; p_probe_out hands back the Newton step.
-int persist_probe(const ascent_params *dp, long batch, int K, double *ws, const double *diterate, const double *dmu, const double *ddw,
+int persist_probe(const ascent_params *dp, long batch, int scheme, int K, double *ws, const double *diterate, const double *dmu, const double *ddw,
                   double *dstep, int *dinertia, hipStream_t stream, char *err, size_t errlen) {
   const PGeo g = geo_of(K);
   const dim3 ng((unsigned)((g.Kp + WAVE - 1) / WAVE), (unsigned)batch);
   hipLaunchKernelGGL(p_init, ng, dim3(WAVE), 0, stream, dp, batch, g, ws, diterate, 2, 0.1, dmu, ddw);
-  hipLaunchKernelGGL(p_solve, dim3((unsigned)((batch + NPW - 1) / NPW)), dim3(WAVE), 0, stream, dp, batch, g, ws, 1000, -1.0);
+  if (scheme == 1) hipLaunchKernelGGL(p_solve<1>, dim3((unsigned)((batch + NPW - 1) / NPW)), dim3(WAVE), 0, stream, dp, batch, g, ws, 1000, -1.0);
+  else hipLaunchKernelGGL(p_solve<0>, dim3((unsigned)((batch + NPW - 1) / NPW)), dim3(WAVE), 0, stream, dp, batch, g, ws, 1000, -1.0);
   hipLaunchKernelGGL(p_probe_out, ng, dim3(WAVE), 0, stream, batch, g, (const double *)ws, dstep, dinertia);
   PCHK2(hipGetLastError());
   return ASCENT_OK;

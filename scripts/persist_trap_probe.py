@@ -1,0 +1,26 @@
+"""Developer check: one round of the persistent kernel, scheme 1 (trapezoid), against the C restatement's Newton step."""
+import sys
+sys.path.insert(0, ".")
+import numpy as np
+import lunar_module_ascent_trajectory_optimiser_amd as A
+from oracle import c_oracle as O
+nt = 60; K = nt - 1
+S = A.sweep_isp_drymass(2, 3)
+for scheme in (0, 1):
+    blobs = []
+    for b, row in enumerate(S):
+        rng = np.random.default_rng(100 + b)
+        r = O.solve_batch(row[None], nt, 3 + b % 4, 1e-9, want_blob=True, coarse_nodes=-1, scheme=scheme)
+        blob = r["blob"][0].copy()
+        blob[8 * K:15 * K] += 0.05 * rng.standard_normal(7 * K)
+        blob[15 * K:21 * K] *= rng.uniform(0.7, 1.3, 6 * K)
+        blobs.append(blob)
+    O.set_scheme(0)
+    blobs = np.stack(blobs, axis=1)
+    mu = np.array([0.1, 0.02, 1e-3, 0.05, 0.01, 0.2]); dw = np.array([0.0, 0.0, 1e-2, 1.0, 0.0, 1e-4])
+    step, inertia = A.kkt_step(S, blobs, mu, dw, nt, path="persist", scheme=scheme)
+    for b in range(len(S)):
+        rc, ref = O.newton_step(S[b], nt, np.ascontiguousarray(blobs[:, b]), mu[b], dw[b], scheme=scheme)
+        O.set_scheme(0)
+        err = [np.abs(step[lo:hi, b] - ref[lo:hi]).max() / max(1.0, np.abs(ref[lo:hi]).max()) for lo, hi in ((0, 7 * K), (7 * K, 8 * K), (8 * K, 15 * K), (15 * K, 21 * K), (21 * K, 21 * K + 10))]
+        print(f"scheme {scheme} NLP {b}: inertia gpu {inertia[b]} oracle {rc}; rel err dz {err[0]:.1e} du {err[1]:.1e} dl {err[2]:.1e} dzb {err[3]:.1e} scal {err[4]:.1e}")

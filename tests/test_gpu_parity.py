@@ -100,7 +100,7 @@ def test_eval_nodes_matches_oracle(coracle, path, scheme, form):
         assert np.all(np.abs(hb[:, (7, 9)] - H[:, (7, 9)]) <= 1e-11 * np.abs(H[:, (7, 9)]) + slack)
 
 
-@pytest.mark.parametrize("path,scheme,form", STEP_CASES + [("persist", 0, 0)])
+@pytest.mark.parametrize("path,scheme,form", STEP_CASES + [("persist", 0, 0), ("persist", 1, 0)])
 def test_kkt_step_matches_oracle(coracle, path, scheme, form):
     """One Newton step of the barrier problem at random interior iterates, with and without primal regularisation,
     through one round of exactly the kernels each path runs in a solve ("persist" = one round of p_solve, the kernel the
@@ -579,3 +579,29 @@ def test_config4_whole_box_on_one_gpu(coracle):
     idx = np.linspace(0, len(full) - 1, 48).astype(int)
     ref = coracle.solve_batch(full[idx], NT, 300, 1e-9)
     assert np.array_equal(r.iters[idx], ref["iters"]) and np.abs(r.tf[idx] - ref["tf"]).max() <= 1e-12
+
+
+def test_persistent_kernel_trapezoid_matches_split_pipeline_and_oracle(coracle, monkeypatch):
+    """scheme 1 (trapezoid, control held over the step) through the persistent kernel -- second evaluation point of every
+    step, pull-back of the value function through Abar = I + (dt/2) F_z in the factorisation, Abar folded into the affine
+    forward / adjoint recursions -- against the split pipeline (which carried the trapezoid in round 1) and the oracle:
+    identical iteration counts on nested grids, t_f to rounding; ragged batches and chunks."""
+    for B, nt in ((5, 200), (67, 200), (1000, 200), (9, 1000)):
+        S = A.sweep_isp_drymass()[:: max(1, 4096 // B)][:B]
+        out = {}
+        for mode in ("persist", "split"):
+            monkeypatch.setenv("ASCENT_PIPELINE", mode)
+            out[mode] = A.solve_batch(S, nt, tol=1e-9, scheme=1, max_iter=500)
+            assert np.all(out[mode].status == 0)
+        assert np.array_equal(out["persist"].iters, out["split"].iters)
+        assert np.abs(out["persist"].tf - out["split"].tf).max() <= 1e-12
+        for f in (0, 1, 2, 3, 6, 9):
+            assert np.abs(out["persist"].traj[f] - out["split"].traj[f]).max() <= 1e-6 * max(1.0, np.abs(out["split"].traj[f]).max())
+        idx = np.linspace(0, B - 1, min(B, 16)).astype(int)
+        ref = coracle.solve_batch(S[idx], nt, 500, 1e-9, scheme=1)
+        coracle.set_scheme(0)
+        assert np.array_equal(out["persist"].iters[idx], ref["iters"]) and np.abs(out["persist"].tf[idx] - ref["tf"]).max() <= 1e-12
+    monkeypatch.delenv("ASCENT_PIPELINE")
+    assert A.default_path(4096, NT, scheme=1) == "persist"
+    r = A.solve_batch(A.AscentParams(), NT, tol=1e-9, scheme=1)
+    assert r.status[0] == 0 and abs(r.final_time()[0] - 435.22714) < 1e-4          # SURVEY Appendix C's independent trapezoid probe: 435.22715 s

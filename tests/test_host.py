@@ -94,16 +94,17 @@ def test_product_does_not_import_oracle():
 
 def test_default_path_dispatch_rule(monkeypatch):
     """ascent_default_path (include/ascent.h): which kernels a solve of that size runs -- no device work, so checked here.
-    Scheme 0: the persistent kernel, except a handful of NLPs on a long grid (>= 400 intervals, batch <= min(8,
-    intervals/75)), which take the dense blocks + PCR; scheme 1: dense blocks up to 8 NLPs, then the split pipeline;
-    scheme 2: dense blocks always."""
+    Schemes 0 and 1: the persistent kernel, except a handful of NLPs on a long grid (>= 400 intervals, batch <= min(8,
+    intervals/75)), which take the dense blocks + PCR; scheme 2: dense blocks always; the v1 formulation: split pipeline."""
     import lunar_module_ascent_trajectory_optimiser_amd as A
     for k in ("ASCENT_PIPELINE", "ASCENT_FACTOR", "ASCENT_SMALL_BATCH", "ASCENT_DENSE_NEWTON"):
         monkeypatch.delenv(k, raising=False)
     assert [A.default_path(b, 201) for b in (1, 9, 4096, 32768, 262144)] == ["persist"] * 5
     assert [A.default_path(b, 2000) for b in (1, 8, 9)] == ["dense", "dense", "persist"]
     assert [A.default_path(b, 401) for b in (1, 5, 6)] == ["dense", "dense", "persist"]
-    assert [A.default_path(b, 201, scheme=1) for b in (8, 9, 4096, 8192)] == ["dense", "split_wide", "split_wide", "split_lane"]
+    assert [A.default_path(b, 201, scheme=1) for b in (1, 8, 4096, 65536)] == ["persist"] * 4
+    assert [A.default_path(b, 2000, scheme=1) for b in (8, 9)] == ["dense", "persist"]
+    assert [A.default_path(b, 201, formulation=1) for b in (4096, 8192)] == ["split_wide", "split_lane"]
     assert A.default_path(4096, 201, scheme=2) == "dense" and A.default_path(4096, 201, formulation=1) == "split_wide"
     assert A.default_path(1, 2000) == "dense"
     monkeypatch.setenv("ASCENT_SMALL_BATCH", "off")
