@@ -121,9 +121,9 @@ const char *ascent_strerror(int code);
  * traj_out [10*n_nodes][batch], tf_out/status_out/iters_out [batch]; sol_blob_out_or_null
  * [21K+10][batch] receives the full primal-dual solution (usable as a warm start).
  * stream: hipStream_t or NULL.  With host pointers the call returns after the results are in the
- * caller's buffers.  With ptr_is_device != 0 and a stream, the persistent kernel (schemes 0 and 1, formulation 0:
- * the default at every batch size; ascent_default_path) is only enqueued -- a handful of launches per grid level, no
- * host involvement; the split pipeline (formulation 1) and the dense-block path (scheme 2, a few NLPs
+ * caller's buffers.  With ptr_is_device != 0 and a stream, the persistent kernel (schemes 0 and 1, both
+ * formulations: the default at every batch size; ascent_default_path) is only enqueued -- a handful of launches per grid level, no
+ * host involvement; the split pipeline (ASCENT_PIPELINE=split) and the dense-block path (scheme 2, a few NLPs
  * on long grids) synchronise the stream once per burst of interior-point rounds, because the host steers the
  * rounds, and return with the last kernels enqueued.
  * Concurrency: host-side, calls on one device are serialised by a mutex.  Device-side, the library keeps a workspace per
@@ -168,7 +168,7 @@ int ascent_kkt_step(const ascent_params *p, int64_t batch, const ascent_opts *o,
 enum ascent_path { ASCENT_PATH_AUTO = 0, ASCENT_PATH_FUSED = 1, ASCENT_PATH_SPLIT_LANE = 2, ASCENT_PATH_SPLIT_WIDE = 3,
                    ASCENT_PATH_DENSE = 4, /* d_eval -> d_newton, one wavefront per NLP on dense 8x8 blocks: schemes 0/1/2 */
                    ASCENT_PATH_PERSIST = 5 /* one round of p_solve, the persistent kernel (ascent_kkt_step_path only: its node
-                                              rows live in LDS; schemes 0 / 1, formulation 0) */ };
+                                              rows live in LDS; schemes 0 / 1, formulation 1 with scheme 0) */ };
 /* Which kernels ascent_solve_batch runs for a batch of this size with these options (and the environment overrides):
  * an ascent_path value, never ASCENT_PATH_AUTO.  No device work. */
 int ascent_default_path(int64_t batch, const ascent_opts *o);

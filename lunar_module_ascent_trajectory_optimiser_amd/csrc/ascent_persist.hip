@@ -19,7 +19,7 @@
 //   * line-search rejections, inertia corrections and the barrier schedule are per-NLP state in LDS; wavefronts do not
 //     wait for one another and the host is not involved until the level is finished; the grid levels of the nested
 //     iteration hand over inside this layout (p_transfer).
-// Backward Euler (the reference's NODES=2) and the trapezoid (p_solve<1>), current formulation.
+// Backward Euler (the reference's NODES=2; p_solve<0,0>), the trapezoid (<1,0>) and the v1 formulation (<0,1>).
 #include <hip/hip_runtime.h>
 
 #include <cstdio>
@@ -59,7 +59,7 @@ enum {
 enum { ST_TRIAL = 0, ST_FACTOR = 1, ST_FACTORED = 2, ST_DONE = 3 };
 
 struct PGeo {
-  int K, Kp, nch;
+  int K, Kp, nch, form;
   __host__ __device__ size_t nlp_doubles() const { return (size_t)NROWS * Kp + NSCAL; }
 };
 
@@ -119,7 +119,7 @@ ASC_DEV Scal trial_scal(const Der &d, const Scal &s, const Scal &ds, double alph
 // ==============================================================================================================
 // The starting point at node kk: the built-in straight-line guess (warm == 0) or the caller's / the coarser grid's values in
 // z, l, u, zb, pushed into the interior (warm 1: primal only, warm 2: primal-dual; a probe takes them as they are)
-ASC_DEV void start_node(const Der &d, int K, int kk, int warm, bool probe, double *z, double *l, double *zb, double &u) {
+ASC_DEV void start_node(const Der &d, int K, int kk, int warm, bool probe, int form, double *z, double *l, double *zb, double &u) {
   if (!warm) {
     const double tf0 = 0.9, dr = 0.166, aend = 0.5, vp = sqrt(d.vp2), dt0 = (1.0 / K) * d.T * tf0;
     const double sdr = sin(dr), cdr = cos(dr);
@@ -128,6 +128,10 @@ ASC_DEV void start_node(const Der &d, int K, int kk, int warm, bool probe, doubl
     z[IX] = fr * xf; z[IY] = fr * yf; z[IVX] = -fr * vp * cdr; z[IVY] = -fr * vp * sdr; z[IA] = fr * aend;
     z[IW] = aend / (K * dt0); z[IM] = d.mrate * dt0 * (kk + 1);
     u = 0.0;
+    if (form == 1) {       // v1: the angle is the control: angle = (ub/2)(u+1), no angular rate
+      z[IW] = 0.0;
+      u = z[IA] / (0.5 * d.aub) - 1.0;
+    }
   }
   if (!probe) {
     z[IA] = push_in(z[IA], 0.0, d.aub);
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(WAVE) void p_init(const ascent_params *params, long
     ASC_UNROLL
     for (int b = 0; b < 6; b++) zb[b] = guess[(15L * K + 6L * kk + b) * batch + p];
   }
-  start_node(d, K, kk, warm, probe, z, l, zb, u);
+  start_node(d, K, kk, warm, probe, g.form, z, l, zb, u);
   store_start(w, Kp, k, z, l, zb, u);
   if (k != K - 1) return;
   double *sc = w + (size_t)NROWS * Kp;
@@ -228,7 +232,7 @@ __global__ __launch_bounds__(WAVE) void p_transfer(const ascent_params *params, 
     const double zsc = (double)Kc / (double)Kf;
     ASC_UNROLL
     for (int i = 0; i < 7; i++) {
-      const double a = j ? ic[(O_Z + i) * Kpc + ja] : 0.0, b = ic[(O_Z + i) * Kpc + j];
+      const double a = j ? ic[(O_Z + i) * Kpc + ja] : ((gf.form == 1 && i == IA) ? ic[(O_Z + i) * Kpc] : 0.0), b = ic[(O_Z + i) * Kpc + j];
       z[i] = fma(wt, b - a, a);
       const double la = ic[(O_L + i) * Kpc + ja], lb = ic[(O_L + i) * Kpc + j];
       l[i] = fma(wt, lb - la, la);
@@ -240,7 +244,7 @@ __global__ __launch_bounds__(WAVE) void p_transfer(const ascent_params *params, 
       zb[b6] = fma(wt, b - a, a) * zsc;
     }
   }
-  start_node(d, Kf, kk, warm, false, z, l, zb, u);
+  start_node(d, Kf, kk, warm, false, gf.form, z, l, zb, u);
   store_start(wf, Kpf, k, z, l, zb, u);
   if (k != Kf - 1) return;
   double *sc = wf + (size_t)NROWS * Kpf;
@@ -354,10 +358,11 @@ ASC_DEV void load_node(const double *it, int Kp, int K, int k, NodeIn &n) {
 
 // Rows xdot and ydot of A^-1, A = I - dt df/dz (see solveA in ascent_device.hpp).  The other rows follow from them:
 // row x = e_x + dt row xdot, row y = e_y + dt row ydot, row angle = e_angle + dt e_angledot; rows angledot and mass are unit vectors.
+template <int FORM>
 ASC_DEV void ainv_vrows(const double *G, const double *E, double dt, double *rvx, double *rvy) {
   double c1[7], c2[7];
-  c1[IX] = dt * G[0]; c1[IY] = dt * G[1]; c1[IVX] = 1.0; c1[IVY] = 0.0; c1[IA] = dt * G[2]; c1[IW] = dt * c1[IA]; c1[IM] = dt * G[3];
-  c2[IX] = dt * G[4]; c2[IY] = dt * G[5]; c2[IVX] = 0.0; c2[IVY] = 1.0; c2[IA] = dt * G[6]; c2[IW] = dt * c2[IA]; c2[IM] = dt * G[7];
+  c1[IX] = dt * G[0]; c1[IY] = dt * G[1]; c1[IVX] = 1.0; c1[IVY] = 0.0; c1[IA] = dt * G[2]; c1[IW] = FORM == 1 ? 0.0 : dt * c1[IA]; c1[IM] = dt * G[3];
+  c2[IX] = dt * G[4]; c2[IY] = dt * G[5]; c2[IVX] = 0.0; c2[IVY] = 1.0; c2[IA] = dt * G[6]; c2[IW] = FORM == 1 ? 0.0 : dt * c2[IA]; c2[IM] = dt * G[7];
   ASC_UNROLL
   for (int i = 0; i < 7; i++) { rvx[i] = E[0] * c1[i] + E[1] * c2[i]; rvy[i] = E[2] * c1[i] + E[3] * c2[i]; }
 }
@@ -379,7 +384,7 @@ struct TrialCtx {       // what the trial point of an NLP needs besides the node
 
 // The trial point x + alpha dx at node k (iterate n, step dn), stored into the other iterate buffer, and its pieces of the
 // l1 merit function and of the KKT error (Launch_Optimiser.py:114-136 evaluated once, with first derivatives).
-template <int SCHEME>
+template <int SCHEME, int FORM>
 ASC_DEV void trial_node(const Der &d, int K, int Kp, int k, const NodeIn &n, const NodeIn &dn, const TrialCtx &t, bool live,
                         double *in, Part &P) {
   const double alpha = t.alpha;
@@ -408,22 +413,22 @@ ASC_DEV void trial_node(const Der &d, int K, int Kp, int k, const NodeIn &n, con
   const double cs = SCHEME == 1 ? 0.5 * t.dt : t.dt;
   double G[8], F[7], fl[7], lt[7], ax, ay;
   accel<1>(d, z[IX], z[IY], z[IA], z[IM], 0.0, 0.0, ax, ay, G, nullptr);
-  rhs_f(d, z, u, ax, ay, F);
+  rhs_f<FORM>(d, z, u, ax, ay, F);
   if (SCHEME == 1) {
     double Fb[7], axp, ayp;
     accel<0>(d, zp[IX], zp[IY], zp[IA], zp[IM], 0.0, 0.0, axp, ayp, nullptr, nullptr);
-    rhs_f(d, zp, u, axp, ayp, Fb);
+    rhs_f<FORM>(d, zp, u, axp, ayp, Fb);
     ASC_UNROLL
     for (int i = 0; i < 7; i++) F[i] = 0.5 * (F[i] + Fb[i]);
   }
   ASC_UNROLL
   for (int i = 0; i < 7; i++) lt[i] = SCHEME == 1 ? l[i] + ln[i] : l[i];
-  fzt_lambda(G, lt, fl);
+  fzt_lambda<FORM>(G, lt, fl);
   double r[7];
   ASC_UNROLL
   for (int i = 0; i < 7; i++) {
-    r[i] = l[i] - cs * fl[i] - ln[i];
-    const double cc = z[i] - zp[i] - t.dt * F[i];
+    r[i] = (FORM == 1 && i == IA) ? l[i] - cs * fl[i] : l[i] - cs * fl[i] - ln[i];
+    const double cc = (FORM == 1 && i == IA) ? z[IA] - 0.5 * d.aub * (u + 1.0) : z[i] - zp[i] - t.dt * F[i];
     P.c1 += fabs(cc);
     P.cinf = fmax(P.cinf, fabs(cc));
     P.rth -= t.hT * F[i] * l[i];
@@ -446,7 +451,7 @@ ASC_DEV void trial_node(const Der &d, int K, int Kp, int k, const NodeIn &n, con
   }
   ASC_UNROLL
   for (int i = 0; i < 7; i++) P.rd = fmax(P.rd, fabs(r[i]));
-  P.rd = fmax(P.rd, fabs(-t.be * l[IW] - zb[4] + zb[5]));
+  P.rd = fmax(P.rd, fabs((FORM == 1 ? -0.5 * d.aub * l[IA] : -t.be * l[IW]) - zb[4] + zb[5]));
   ASC_UNROLL
   for (int b = 0; b < 6; b++) { const double pr = dist[b] * zb[b]; P.pmin = fmin(P.pmin, pr); P.pmax = fmax(P.pmax, pr); P.zsum += zb[b]; }
   const double pa = dist[0] * dist[1], pm = dist[2] * dist[3], pu = dist[4] * dist[5];
@@ -463,7 +468,7 @@ ASC_DEV void trial_node(const Der &d, int K, int Kp, int k, const NodeIn &n, con
 #define PROF_END do { } while (0)
 #endif
 
-template <int SCHEME>
+template <int SCHEME, int FORM>
 __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, long batch, PGeo g, double *ws, int max_iter, double tol) {
   __shared__ double stage[S_ROWS * LDW];
   __shared__ double outb[OUT_ROWS * LDW];
@@ -487,7 +492,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
   wsync();
   const int col = grp * 16 + role;                      // this lane's column of the LDS stage in node-parallel phases
   const double hT = (1.0 / K) * d.T;
-  constexpr int IB = IW;
+  constexpr int IB = FORM == 1 ? IA : IW;          // the defect row the control enters (v1: the algebraic angle row)
 
   PROF_DECL
   for (int round = 0; round < 64 * (max_iter + 2); round++) {
@@ -520,7 +525,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             load_node(ic, Kp, K, k, n);
             if (first) dn = NodeIn{};             // (no step yet; the step rows are not initialised)
             else load_node(stp, Kp, K, k, dn);
-            trial_node<SCHEME>(d, K, Kp, k, n, dn, t, live, in, P);
+            trial_node<SCHEME, FORM>(d, K, Kp, k, n, dn, t, live, in, P);
           }
         }
         P.reduce16();
@@ -588,7 +593,8 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
       const Scal s = lds_scal(sc, X_S);
       const double mu = sc[X_MU], dw = sc[X_DW];
       const double *it = w + (size_t)((int)sc[X_CUR] * NIT) * Kp;
-      const double dt = hT * s.th, be = dt * d.alpha, ith = rcp(s.th), cs = SCHEME == 1 ? 0.5 * dt : dt, bu = be;
+      const double dt = hT * s.th, be = dt * d.alpha, ith = rcp(s.th), cs = SCHEME == 1 ? 0.5 * dt : dt;
+      const double ha = 0.5 * d.aub, bu = FORM == 1 ? ha : be;          // (v1: angle = ha (u + 1), the control enters the angle row)
       const double hTc = SCHEME == 1 ? 0.5 * hT : hT;
       // what this lane gathers from a step's blocks for row i of its vector (factor phase), as in q_factor_wide
       int grow[7];
@@ -657,16 +663,16 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             ASC_UNROLL
             for (int i = 0; i < 7; i++) lt[i] = SCHEME == 1 ? n.l[i] + n.ln[i] : n.l[i];
             accel<2>(d, n.z[IX], n.z[IY], n.z[IA], n.z[IM], -cs * lt[IVX], -cs * lt[IVY], ax, ay, G, H);
-            rhs_f(d, n.z, n.u, ax, ay, F);
+            rhs_f<FORM>(d, n.z, n.u, ax, ay, F);
             if (SCHEME == 1) {       // second evaluation point of the step: f(z_{k-1}, u_k)
               double Fb[7], axp, ayp;
               accel<0>(d, n.zp[IX], n.zp[IY], n.zp[IA], n.zp[IM], 0.0, 0.0, axp, ayp, nullptr, nullptr);
-              rhs_f(d, n.zp, n.u, axp, ayp, Fb);
+              rhs_f<FORM>(d, n.zp, n.u, axp, ayp, Fb);
               ASC_UNROLL
               for (int i = 0; i < 7; i++) F[i] = 0.5 * (F[i] + Fb[i]);
             }
             implicit_block(G, cs, E);
-            fzt_lambda(G, lt, fl);
+            fzt_lambda<FORM>(G, lt, fl);
             const double dist[6] = {n.z[IA], d.aub - n.z[IA], n.z[IM], 1.0 - n.z[IM], n.u + 1.0, 1.0 - n.u};
             double id[6];
             ASC_UNROLL
@@ -682,11 +688,12 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             ASC_UNROLL
             for (int i = 0; i < 7; i++) {
               stage[(S_F + i) * LDW + col] = hT * F[i];            // (pre-scaled: the sweep uses hT F only)
-              stage[(S_C + i) * LDW + col] = n.z[i] - n.zp[i] - dt * F[i];
-              stage[(S_RZ + i) * LDW + col] = n.l[i] - cs * fl[i] - n.ln[i];
+              stage[(S_C + i) * LDW + col] = (FORM == 1 && i == IA) ? n.z[IA] - ha * (n.u + 1.0) : n.z[i] - n.zp[i] - dt * F[i];
+              stage[(S_RZ + i) * LDW + col] = (FORM == 1 && i == IA) ? n.l[i] - cs * fl[i] : n.l[i] - cs * fl[i] - n.ln[i];
               stage[(S_GT + i) * LDW + col] = -hTc * fl[i];
             }
-            const double scr[5] = {n.zb[4] * id[4] + n.zb[5] * id[5], -be * n.l[IW], id[1] - id[0], id[3] - id[2], id[5] - id[4]};
+            const double scr[5] = {n.zb[4] * id[4] + n.zb[5] * id[5], FORM == 1 ? -ha * n.l[IA] : -be * n.l[IW], id[1] - id[0], id[3] - id[2],
+                                   id[5] - id[4]};
             ASC_UNROLL
             for (int i = 0; i < 5; i++) stage[(S_SC + i) * LDW + col] = scr[i];
           }
@@ -712,6 +719,13 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
                                   bcast16<4>(gB), bcast16<5>(gB), bcast16<6>(gB)};
             const double rc1[7] = {bcast16<7>(gB), bcast16<8>(gB), bcast16<9>(gB), bcast16<10>(gB), bcast16<11>(gB),
                                    bcast16<12>(gB), bcast16<13>(gB)};
+            if (FORM == 1 && k < K - 1) {     // step k+1 does not see angle_k: drop its row and column
+              a[IA] = 0.0;
+              if (role == IA) {
+                ASC_UNROLL
+                for (int i = 0; i < 7; i++) a[i] = 0.0;
+              }
+            }
             if (SCHEME == 1 && k < K - 1) {   // pull the value function of step k+1 back through Abar = I + cs F_z(z_k): Abar' on every
               double t[7];                    // column and right-hand side, transpose, Abar' on the columns again
               fzt_lambda(G, a, t);
@@ -739,7 +753,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
               for (int i = 0; i < 7; i++) a[i] += role == i ? dw : 0.0;
             }
             double b[7];
-            solveAT<0>(G, E, cs, a, b);
+            solveAT<FORM>(G, E, cs, a, b);
             if (colr) {       // N <- A^-T N A^-1: the columns, transposed through LDS (in order within a wavefront), the columns again
               ASC_UNROLL
               for (int i = 0; i < 7; i++) lds_t[grp][role][i] = b[i];
@@ -747,14 +761,14 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
               double t[7];
               ASC_UNROLL
               for (int l2 = 0; l2 < 7; l2++) t[l2] = lds_t[grp][l2][role];
-              solveAT<0>(G, E, cs, t, b);
+              solveAT<FORM>(G, E, cs, t, b);
             }
             double mw[7];
             ASC_UNROLL
             for (int i = 0; i < 7; i++) mw[i] = bu * bcast16<IB>(b[i]);
             const double D = R0 + dw + bu * mw[IB];
             const double iD = rcp(D);
-            const double ru = ru0 + mu * bur, gu = ru0 * ith;
+            const double ru = ru0 + mu * bur, gu = FORM == 1 ? 0.0 : ru0 * ith;
             const double rsel = role == 7 ? ru : role == 8 ? gu : 0.0;
             const double coef = (bu * b[IB] - rsel) * iD;
             ASC_UNROLL
@@ -855,6 +869,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
       const double *it = w + (size_t)((int)sc[X_CUR] * NIT) * Kp;
       double *stp = w + (size_t)R_ST * Kp;
       const double dt = hT * s.th, be = dt * d.alpha, cs = SCHEME == 1 ? 0.5 * dt : dt, hTc = SCHEME == 1 ? 0.5 * hT : hT;
+      const double ha = 0.5 * d.aub, bu = FORM == 1 ? ha : be;
       const double tau = fmax(0.99, 1.0 - mu);
       // ---- forward -----------------------------------------------------------------------------------------------
       {
@@ -888,18 +903,18 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             for (int i = 0; i < 7; i++) ka[i] = w[(size_t)(R_KA + i) * Kp + kn];
             du00 = w[(size_t)R_K0 * Kp + kn] + w[(size_t)(R_K0 + 1) * Kp + kn] * dth + w[(size_t)(R_K0 + 2) * Kp + kn] * dnu3;
             accel<1>(d, z[IX], z[IY], z[IA], z[IM], 0.0, 0.0, ax, ay, G, nullptr);
-            rhs_f(d, z, u_, ax, ay, F);
+            rhs_f<FORM>(d, z, u_, ax, ay, F);
             if (SCHEME == 1) {       // second evaluation point f(z_{k-1}, u_k); its Jacobian is the Abar_k = I + cs F_z(z_{k-1}) of the step
               double Fb[7], axp, ayp;
               accel<1>(d, zp[IX], zp[IY], zp[IA], zp[IM], 0.0, 0.0, axp, ayp, Gp, nullptr);
-              rhs_f(d, zp, u_, axp, ayp, Fb);
+              rhs_f<FORM>(d, zp, u_, axp, ayp, Fb);
               ASC_UNROLL
               for (int i = 0; i < 7; i++) F[i] = 0.5 * (F[i] + Fb[i]);
             }
             implicit_block(G, cs, E);
             ASC_UNROLL
             for (int i = 0; i < 7; i++) {
-              x0[i] = hT * F[i] * dth - (z[i] - zp[i] - dt * F[i]);
+              x0[i] = hT * F[i] * dth - ((FORM == 1 && i == IA) ? z[IA] - ha * (u_ + 1.0) : z[i] - zp[i] - dt * F[i]);
               du00 -= ka[i] * x0[i];
             }
           }
@@ -915,10 +930,10 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
           if (on) {
             const double du00p = du00 - ka[IM] * dzm_p;
             double rvx[7], rvy[7];
-            ainv_vrows(G, E, cs, rvx, rvy);
+            ainv_vrows<FORM>(G, E, cs, rvx, rvy);
             // row i of M = (row i of A^-1) - be aW[i] ka',  v[i] = (row i of A^-1) . x0 + be aW[i] du00' + A^-1[i][m] dz_m,k-1,  aW = A^-1 e_w
             auto emit = [&](int i, const double *r, double aw) {
-              const double bw = be * aw;
+              const double bw = bu * aw;
               if (SCHEME == 1) {       // dz_k = M Abar_k dz_{k-1} + v: the row times Abar (= row + cs F_z' row), its mass entry folded into v
                 double m7[7], t[7];
                 ASC_UNROLL
@@ -938,25 +953,26 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
               ASC_UNROLL
               for (int j = 0; j < 7; j++) v += r[j] * x0[j];
               ASC_UNROLL
-              for (int j = 0; j < 6; j++) stage[(7 * i + j) * LDW + col] = r[j] - bw * ka[j];
+              for (int j = 0; j < 6; j++) stage[(7 * i + j) * LDW + col] = (FORM == 1 && j == IA) ? 0.0 : r[j] - bw * ka[j];     // (v1: no coupling to angle_{k-1})
               stage[(7 * i + 6) * LDW + col] = v;
             };
-            emit(IVX, rvx, rvx[IW]);
-            emit(IVY, rvy, rvy[IW]);
+            // (aW above is A^-1 e_b with b the row the control enters: angledot, or the algebraic angle row of the v1 formulation)
+            emit(IVX, rvx, rvx[IB]);
+            emit(IVY, rvy, rvy[IB]);
             {
               double r[7];
               ASC_UNROLL
               for (int j = 0; j < 7; j++) r[j] = (j == IX ? 1.0 : 0.0) + cs * rvx[j];
-              emit(IX, r, cs * rvx[IW]);
+              emit(IX, r, cs * rvx[IB]);
               ASC_UNROLL
               for (int j = 0; j < 7; j++) r[j] = (j == IY ? 1.0 : 0.0) + cs * rvy[j];
-              emit(IY, r, cs * rvy[IW]);
+              emit(IY, r, cs * rvy[IB]);
               ASC_UNROLL
-              for (int j = 0; j < 7; j++) r[j] = j == IA ? 1.0 : j == IW ? cs : 0.0;
-              emit(IA, r, cs);
+              for (int j = 0; j < 7; j++) r[j] = j == IA ? 1.0 : (j == IW && FORM == 0) ? cs : 0.0;
+              emit(IA, r, FORM == 1 ? 1.0 : cs);
               ASC_UNROLL
               for (int j = 0; j < 7; j++) r[j] = j == IW ? 1.0 : 0.0;
-              emit(IW, r, 1.0);
+              emit(IW, r, FORM == 1 ? 0.0 : 1.0);
             }
             if (SCHEME == 1) {         // du_k = du00 - ka' Abar_k dz_{k-1}
               double t[7];
@@ -966,7 +982,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
               stage[48 * LDW + col] = du00 - (ka[IM] + cs * t[IM]) * dzm_p;
             } else {
               ASC_UNROLL
-              for (int j = 0; j < 6; j++) stage[(42 + j) * LDW + col] = -ka[j];
+              for (int j = 0; j < 6; j++) stage[(42 + j) * LDW + col] = (FORM == 1 && j == IA) ? 0.0 : -ka[j];
               stage[48 * LDW + col] = du00p;
             }
             outb[6 * LDW + col] = dzm_k;
@@ -1079,25 +1095,25 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             ASC_UNROLL
             for (int i = 0; i < 7; i++) lt[i] = SCHEME == 1 ? n.l[i] + n.ln[i] : n.l[i];
             accel<2>(d, n.z[IX], n.z[IY], n.z[IA], n.z[IM], -cs * lt[IVX], -cs * lt[IVY], ax, ay, G, H);
-            rhs_f(d, n.z, n.u, ax, ay, F);
+            rhs_f<FORM>(d, n.z, n.u, ax, ay, F);
             if (SCHEME == 1) {
               double Fb[7], axp, ayp;
               accel<0>(d, n.zp[IX], n.zp[IY], n.zp[IA], n.zp[IM], 0.0, 0.0, axp, ayp, nullptr, nullptr);
-              rhs_f(d, n.zp, n.u, axp, ayp, Fb);
+              rhs_f<FORM>(d, n.zp, n.u, axp, ayp, Fb);
               ASC_UNROLL
               for (int i = 0; i < 7; i++) F[i] = 0.5 * (F[i] + Fb[i]);
             }
             implicit_block(G, cs, E);
-            fzt_lambda(G, lt, fl);
+            fzt_lambda<FORM>(G, lt, fl);
             const double id0 = rcp(n.z[IA]), id1 = rcp(d.aub - n.z[IA]), id2 = rcp(n.z[IM]), id3 = rcp(1.0 - n.z[IM]);
             H[7] += n.zb[0] * id0 + n.zb[1] * id1;
             H[9] += n.zb[2] * id2 + n.zb[3] * id3;
             double r[7];
             ASC_UNROLL
             for (int i = 0; i < 7; i++) {
-              const double rz = n.l[i] - cs * fl[i] - n.ln[i], gt = -hTc * fl[i];
+              const double rz = (FORM == 1 && i == IA) ? n.l[i] - cs * fl[i] : n.l[i] - cs * fl[i] - n.ln[i], gt = -hTc * fl[i];
               r[i] = -rz - gt * dth - dw * dz[i];
-              ccn[i] = n.z[i] - n.zp[i] - dt * F[i];
+              ccn[i] = (FORM == 1 && i == IA) ? n.z[IA] - ha * (n.u + 1.0) : n.z[i] - n.zp[i] - dt * F[i];
               ccl += ccn[i] * n.l[i];
             }
             r[IA] -= mu * (id1 - id0);
@@ -1122,17 +1138,17 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
               r[IVY] -= s.nu3 * tm.e3g[3] + w2 * tm.g2g[1] + tm.e3g[3] * dnu3;
             }
             double wv[7];
-            solveAT<0>(G, E, cs, r, wv);
+            solveAT<FORM>(G, E, cs, r, wv);
             {     // N = A^-T: N[i][j] = A^-1[j][i], j = x y xdot ydot angle (the rows of A^-1 above)
               double rvx[7], rvy[7];
-              ainv_vrows(G, E, cs, rvx, rvy);
+              ainv_vrows<FORM>(G, E, cs, rvx, rvy);
               ASC_UNROLL
               for (int i = 0; i < 7; i++) {
                 double nr[7];             // row i of A^-T
                 nr[IVX] = rvx[i]; nr[IVY] = rvy[i];
                 nr[IX] = (i == IX ? 1.0 : 0.0) + cs * rvx[i];
                 nr[IY] = (i == IY ? 1.0 : 0.0) + cs * rvy[i];
-                nr[IA] = i == IA ? 1.0 : i == IW ? cs : 0.0;
+                nr[IA] = FORM == 1 ? 0.0 : i == IA ? 1.0 : i == IW ? cs : 0.0;      // (v1: no coupling to the angle multiplier of step k+1)
                 nr[IW] = i == IW ? 1.0 : 0.0;
                 nr[IM] = i == IM ? 1.0 : 0.0;
                 if (SCHEME == 1) {      // dl_k = A_k^-T (r_k + Abar_{k+1}' dl_{k+1}),  Abar_{k+1} = I + cs F_z(z_k): the row times Abar'
@@ -1183,7 +1199,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
               ASC_UNROLL
               for (int i = 0; i < 7; i++) lds_c[grp][i] = dn.l[i];
             }
-            trial_node<SCHEME>(d, K, Kp, kn, n, dn, tc, live, in, P);
+            trial_node<SCHEME, FORM>(d, K, Kp, kn, n, dn, tc, live, in, P);
           }
           PROF(0);
         }
@@ -1231,9 +1247,9 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
 
 namespace ascent {
 
-static PGeo geo_of(int K) {
+static PGeo geo_of(int K, int form = 0) {
   PGeo g;
-  g.K = K; g.nch = (K + CH - 1) / CH; g.Kp = g.nch * CH;
+  g.K = K; g.nch = (K + CH - 1) / CH; g.Kp = g.nch * CH; g.form = form;
   return g;
 }
 
@@ -1245,7 +1261,7 @@ int persist_run(const ascent_params *dp, long batch, int K, double *ws, const do
                 double mu0, double *dtraj, double *dtf, int *dstatus, int *diters, double *dblob, hipStream_t stream, char *err,
                 size_t errlen) {
   const int levels[1] = {K + 1};
-  return persist_run_nested(dp, batch, 0, levels, 1, ws, dguess, warm, max_iter, tol, tol, mu0, 0.0, 0.0, dtraj, dtf, dstatus, diters, dblob,
+  return persist_run_nested(dp, batch, 0, 0, levels, 1, ws, dguess, warm, max_iter, tol, tol, mu0, 0.0, 0.0, dtraj, dtf, dstatus, diters, dblob,
                             stream, err, errlen);
 }
 
@@ -1258,19 +1274,20 @@ size_t persist_ws_bytes_nested(const int *levels, int nlev, long batch) {
 // All grid levels of the nested iteration (levels[0] = the requested grid, finest first; the coarsest is solved first, cold or
 // from the caller's guess): p_init, then per level p_solve and p_transfer to the next finer grid, p_finish at the end.  Two
 // workspace regions alternate between the levels.
-int persist_run_nested(const ascent_params *dp, long batch, int scheme, const int *levels, int nlev, double *ws, const double *dguess, int warm,
+int persist_run_nested(const ascent_params *dp, long batch, int scheme, int form, const int *levels, int nlev, double *ws, const double *dguess, int warm,
                        int max_iter, double tol, double tol_coarse, double mu0, double mu_first, double mu_next, double *dtraj,
                        double *dtf, int *dstatus, int *diters, double *dblob, hipStream_t stream, char *err, size_t errlen) {
   double *region[2] = {ws, (double *)((char *)ws + ((persist_ws_bytes(levels[0] - 1, batch) + 255) & ~(size_t)255))};
-  PGeo g = geo_of(levels[nlev - 1] - 1);
+  PGeo g = geo_of(levels[nlev - 1] - 1, form);
   double *w = region[(nlev - 1) & 1];
   hipLaunchKernelGGL(p_init, dim3((unsigned)((g.Kp + WAVE - 1) / WAVE), (unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g, w, dguess,
                      warm, mu0, (const double *)nullptr, (const double *)nullptr);
   for (int l = nlev - 1; l >= 0; l--) {
-    if (scheme == 1) hipLaunchKernelGGL(p_solve<1>, dim3((unsigned)((batch + NPW - 1) / NPW)), dim3(WAVE), 0, stream, dp, batch, g, w, max_iter, l == 0 ? tol : tol_coarse);
-    else hipLaunchKernelGGL(p_solve<0>, dim3((unsigned)((batch + NPW - 1) / NPW)), dim3(WAVE), 0, stream, dp, batch, g, w, max_iter, l == 0 ? tol : tol_coarse);
+    if (scheme == 1) hipLaunchKernelGGL((p_solve<1, 0>), dim3((unsigned)((batch + NPW - 1) / NPW)), dim3(WAVE), 0, stream, dp, batch, g, w, max_iter, l == 0 ? tol : tol_coarse);
+    else if (form == 1) hipLaunchKernelGGL((p_solve<0, 1>), dim3((unsigned)((batch + NPW - 1) / NPW)), dim3(WAVE), 0, stream, dp, batch, g, w, max_iter, l == 0 ? tol : tol_coarse);
+    else hipLaunchKernelGGL((p_solve<0, 0>), dim3((unsigned)((batch + NPW - 1) / NPW)), dim3(WAVE), 0, stream, dp, batch, g, w, max_iter, l == 0 ? tol : tol_coarse);
     if (l > 0) {
-      const PGeo gf = geo_of(levels[l - 1] - 1);
+      const PGeo gf = geo_of(levels[l - 1] - 1, form);
       double *wf = region[(l - 1) & 1];
       hipLaunchKernelGGL(p_transfer, dim3((unsigned)((gf.Kp + WAVE - 1) / WAVE), (unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g,
                          (const double *)w, gf, wf, l == nlev - 1 ? mu_first : mu_next);
@@ -1285,13 +1302,14 @@ int persist_run_nested(const ascent_params *dp, long batch, int scheme, const in
 
 // One round of p_solve at a caller-supplied iterate (parity surface ascent_kkt_step_path): the iterate as it is, mu and
 // delta_w per problem from the caller; p_probe_out hands back the Newton step.
-int persist_probe(const ascent_params *dp, long batch, int scheme, int K, double *ws, const double *diterate, const double *dmu, const double *ddw,
+int persist_probe(const ascent_params *dp, long batch, int scheme, int form, int K, double *ws, const double *diterate, const double *dmu, const double *ddw,
                   double *dstep, int *dinertia, hipStream_t stream, char *err, size_t errlen) {
-  const PGeo g = geo_of(K);
+  const PGeo g = geo_of(K, form);
   const dim3 ng((unsigned)((g.Kp + WAVE - 1) / WAVE), (unsigned)batch);
   hipLaunchKernelGGL(p_init, ng, dim3(WAVE), 0, stream, dp, batch, g, ws, diterate, 2, 0.1, dmu, ddw);
-  if (scheme == 1) hipLaunchKernelGGL(p_solve<1>, dim3((unsigned)((batch + NPW - 1) / NPW)), dim3(WAVE), 0, stream, dp, batch, g, ws, 1000, -1.0);
-  else hipLaunchKernelGGL(p_solve<0>, dim3((unsigned)((batch + NPW - 1) / NPW)), dim3(WAVE), 0, stream, dp, batch, g, ws, 1000, -1.0);
+  if (scheme == 1) hipLaunchKernelGGL((p_solve<1, 0>), dim3((unsigned)((batch + NPW - 1) / NPW)), dim3(WAVE), 0, stream, dp, batch, g, ws, 1000, -1.0);
+  else if (form == 1) hipLaunchKernelGGL((p_solve<0, 1>), dim3((unsigned)((batch + NPW - 1) / NPW)), dim3(WAVE), 0, stream, dp, batch, g, ws, 1000, -1.0);
+  else hipLaunchKernelGGL((p_solve<0, 0>), dim3((unsigned)((batch + NPW - 1) / NPW)), dim3(WAVE), 0, stream, dp, batch, g, ws, 1000, -1.0);
   hipLaunchKernelGGL(p_probe_out, ng, dim3(WAVE), 0, stream, batch, g, (const double *)ws, dstep, dinertia);
   PCHK2(hipGetLastError());
   return ASCENT_OK;

@@ -17,13 +17,13 @@ int persist_run(const ascent_params *dp, long batch, int K, double *ws, const do
 // The whole nested iteration inside the kernel's own layout: levels[0] = the requested grid (nodes), finest first; coarse levels
 // are solved to tol_coarse; a level warm-started from the coarsest grid begins at mu_first, later ones at mu_next.
 size_t persist_ws_bytes_nested(const int *levels, int nlev, long batch);
-int persist_run_nested(const ascent_params *dp, long batch, int scheme, const int *levels, int nlev, double *ws, const double *dguess, int warm,
+int persist_run_nested(const ascent_params *dp, long batch, int scheme, int form, const int *levels, int nlev, double *ws, const double *dguess, int warm,
                        int max_iter, double tol, double tol_coarse, double mu0, double mu_first, double mu_next, double *dtraj,
                        double *dtf, int *dstatus, int *diters, double *dblob, hipStream_t stream, char *err, size_t errlen);
 
 // One interior-point round of the same kernel at a caller-supplied iterate, mu and delta_w (parity surface): the Newton step in
 // the blob layout, inertia[p] = 1 where the factorisation was refused.
-int persist_probe(const ascent_params *dp, long batch, int scheme, int K, double *ws, const double *diterate, const double *dmu, const double *ddw,
+int persist_probe(const ascent_params *dp, long batch, int scheme, int form, int K, double *ws, const double *diterate, const double *dmu, const double *ddw,
                   double *dstep, int *dinertia, hipStream_t stream, char *err, size_t errlen);
 
 }  // namespace ascent

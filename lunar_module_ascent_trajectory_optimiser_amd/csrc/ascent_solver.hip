@@ -950,9 +950,9 @@ bool use_pcr_newton(int64_t batch) {
 }
 
 // The persistent kernel (ascent_persist.hip: one wavefront owns four NLPs for the whole solve, node blocks handed from the
-// node-parallel phases to the serial sweeps through LDS) -- backward Euler and trapezoid, current formulation.
+// node-parallel phases to the serial sweeps through LDS) -- backward Euler (both formulations) and the trapezoid.
 bool use_persist_path(const ascent_opts *o, int64_t batch) {
-  if (o->scheme > 1 || o->formulation != 0) return false;
+  if (o->scheme > 1 || (o->formulation != 0 && o->scheme != 0)) return false;
   const char *e = getenv("ASCENT_PIPELINE");
   if (e) return !strcmp(e, "persist");
   if (getenv("ASCENT_FACTOR")) return false;          // an explicit choice between the split pipeline's sweep kernels
@@ -1132,7 +1132,6 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
   const int K = o->n_nodes - 1, nt = o->n_nodes;
   const size_t rows = 21 * (size_t)K + NSC;
   const int lpt = lanes_per_tile(batch);
-  // (the v1 formulation exists in the split pipeline only)
   const bool dense = use_dense_path(o, batch);
   const bool pcr = dense && use_pcr_newton(batch);
   const bool persist = !dense && use_persist_path(o, batch);
@@ -1203,7 +1202,7 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
   }
   HIPCHK(hipEventRecord(w.ev0, stream));
   if (persist) {      // all levels inside the kernel's own layout
-    rc = persist_run_nested(dp, (long)batch, (int)o->scheme, levels, nlev, w.ws, dguess, (int)o->warm_start, (int)o->max_iter, o->tol,
+    rc = persist_run_nested(dp, (long)batch, (int)o->scheme, (int)o->formulation, levels, nlev, w.ws, dguess, (int)o->warm_start, (int)o->max_iter, o->tol,
                             fmax(o->tol, NESTED_COARSE_TOL), mu0, NESTED_MU_FIRST, nested_mu_next(o->tol), dtraj, dtf, dstatus, diters,
                             dblob, stream, g_err, sizeof g_err);
     if (rc) return rc;
@@ -1326,7 +1325,7 @@ int ascent_kkt_step_path(const ascent_params *p, int64_t batch, const ascent_opt
   if (path < ASCENT_PATH_AUTO || path > ASCENT_PATH_PERSIST) { snprintf(g_err, sizeof g_err, "unknown path %d", path); return ASCENT_E_ARG; }
   path = resolve_path(path, o, batch, true);
   if (o->scheme == 2 && path != ASCENT_PATH_DENSE) { snprintf(g_err, sizeof g_err, "scheme 2 exists in the dense-block path only"); return ASCENT_E_ARG; }
-  if (path == ASCENT_PATH_PERSIST && (o->scheme > 1 || o->formulation != 0)) { snprintf(g_err, sizeof g_err, "the persistent kernel has schemes 0 and 1, formulation 0 only"); return ASCENT_E_ARG; }
+  if (path == ASCENT_PATH_PERSIST && (o->scheme > 1 || (o->scheme == 1 && o->formulation != 0))) { snprintf(g_err, sizeof g_err, "the persistent kernel has schemes 0 and 1 (formulation 1 with scheme 0 only)"); return ASCENT_E_ARG; }
   if (path == ASCENT_PATH_DENSE && o->formulation != 0) { snprintf(g_err, sizeof g_err, "the dense-block path has formulation 0 only"); return ASCENT_E_ARG; }
   if (path == ASCENT_PATH_FUSED && (o->scheme != 0 || o->formulation != 0)) { snprintf(g_err, sizeof g_err, "the fused path has scheme 0, formulation 0 only"); return ASCENT_E_ARG; }
   std::lock_guard<std::mutex> lock(g_mu[device_id]);
@@ -1357,7 +1356,7 @@ int ascent_kkt_step_path(const ascent_params *p, int64_t batch, const ascent_opt
                      0, g_err, sizeof g_err, pcr_probe ? 1 : 0);
     if (rc) return rc;
   } else if (path == ASCENT_PATH_PERSIST) {
-    rc = persist_probe(bp.d, (long)batch, (int)o->scheme, K, g_ws_slot0(device_id).ws, bit.d, bmu.d, bdw.d, bst.d, bin.d, 0, g_err, sizeof g_err);
+    rc = persist_probe(bp.d, (long)batch, (int)o->scheme, (int)o->formulation, K, g_ws_slot0(device_id).ws, bit.d, bmu.d, bdw.d, bst.d, bin.d, 0, g_err, sizeof g_err);
     if (rc) return rc;
   } else if (path == ASCENT_PATH_FUSED) {
     hipLaunchKernelGGL(k_kkt_step, dim3((unsigned)((batch + lpt - 1) / lpt)), dim3(WAVE), 0, 0, bp.d, (long)batch, lpt, K,

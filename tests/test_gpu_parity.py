@@ -100,7 +100,7 @@ def test_eval_nodes_matches_oracle(coracle, path, scheme, form):
         assert np.all(np.abs(hb[:, (7, 9)] - H[:, (7, 9)]) <= 1e-11 * np.abs(H[:, (7, 9)]) + slack)
 
 
-@pytest.mark.parametrize("path,scheme,form", STEP_CASES + [("persist", 0, 0), ("persist", 1, 0)])
+@pytest.mark.parametrize("path,scheme,form", STEP_CASES + [("persist", 0, 0), ("persist", 1, 0), ("persist", 0, 1)])
 def test_kkt_step_matches_oracle(coracle, path, scheme, form):
     """One Newton step of the barrier problem at random interior iterates, with and without primal regularisation,
     through one round of exactly the kernels each path runs in a solve ("persist" = one round of p_solve, the kernel the
@@ -605,3 +605,28 @@ def test_persistent_kernel_trapezoid_matches_split_pipeline_and_oracle(coracle, 
     assert A.default_path(4096, NT, scheme=1) == "persist"
     r = A.solve_batch(A.AscentParams(), NT, tol=1e-9, scheme=1)
     assert r.status[0] == 0 and abs(r.final_time()[0] - 435.22714) < 1e-4          # SURVEY Appendix C's independent trapezoid probe: 435.22715 s
+
+
+def test_persistent_kernel_v1_formulation_matches_split_pipeline_and_oracle(coracle, monkeypatch):
+    """formulation 1 (the v1 script of the PDF appendix: the angle itself is the MV, an algebraic row without coupling to the
+    previous step) through the persistent kernel: identical iteration counts and t_f to rounding against the split pipeline and
+    the oracle, single grids and nested ones; the second golden vector through the default dispatch."""
+    base = A.AscentParams(**V1)
+    for shape, nt in (((1, 1), 200), ((3, 2), 200), ((13, 10), 37), ((32, 32), 200), ((3, 3), 1000)):
+        S = A.sweep_isp_drymass(*shape, base=base)
+        out = {}
+        for mode in ("persist", "split"):
+            monkeypatch.setenv("ASCENT_PIPELINE", mode)
+            out[mode] = A.solve_batch(S, nt, tol=1e-9, formulation="v1", max_iter=500)
+            assert np.all(out[mode].status == 0)
+        assert np.array_equal(out["persist"].iters, out["split"].iters)
+        assert np.abs(out["persist"].tf - out["split"].tf).max() <= 1e-12
+        assert np.abs(out["persist"].traj - out["split"].traj).max() <= 1e-9
+        idx = np.linspace(0, len(S) - 1, min(len(S), 16)).astype(int)
+        ref = coracle.solve_batch(S[idx], nt, 500, 1e-9, formulation=1)
+        coracle.set_formulation(0)
+        assert np.array_equal(out["persist"].iters[idx], ref["iters"]) and np.abs(out["persist"].tf[idx] - ref["tf"]).max() <= 1e-12
+    monkeypatch.delenv("ASCENT_PIPELINE")
+    assert A.default_path(1, NT, formulation=1) == "persist"
+    v = A.solve_batch(base, NT, tol=1e-9, formulation="v1", max_iter=500)
+    assert v.status[0] == 0 and abs(v.final_time()[0] - 435.29773) < 2e-3        # PDF p30: 435.29773 s (here 435.29896)

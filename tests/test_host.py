@@ -94,8 +94,8 @@ def test_product_does_not_import_oracle():
 
 def test_default_path_dispatch_rule(monkeypatch):
     """ascent_default_path (include/ascent.h): which kernels a solve of that size runs -- no device work, so checked here.
-    Schemes 0 and 1: the persistent kernel, except a handful of NLPs on a long grid (>= 400 intervals, batch <= min(8,
-    intervals/75)), which take the dense blocks + PCR; scheme 2: dense blocks always; the v1 formulation: split pipeline."""
+    Schemes 0 and 1 and the v1 formulation: the persistent kernel, except (formulation 0) a handful of NLPs on a long grid
+    (>= 400 intervals, batch <= min(8, intervals/75)), which take the dense blocks + PCR; scheme 2: dense blocks always."""
     import lunar_module_ascent_trajectory_optimiser_amd as A
     for k in ("ASCENT_PIPELINE", "ASCENT_FACTOR", "ASCENT_SMALL_BATCH", "ASCENT_DENSE_NEWTON"):
         monkeypatch.delenv(k, raising=False)
@@ -104,8 +104,8 @@ def test_default_path_dispatch_rule(monkeypatch):
     assert [A.default_path(b, 401) for b in (1, 5, 6)] == ["dense", "dense", "persist"]
     assert [A.default_path(b, 201, scheme=1) for b in (1, 8, 4096, 65536)] == ["persist"] * 4
     assert [A.default_path(b, 2000, scheme=1) for b in (8, 9)] == ["dense", "persist"]
-    assert [A.default_path(b, 201, formulation=1) for b in (4096, 8192)] == ["split_wide", "split_lane"]
-    assert A.default_path(4096, 201, scheme=2) == "dense" and A.default_path(4096, 201, formulation=1) == "split_wide"
+    assert [A.default_path(b, 201, formulation=1) for b in (1, 4096, 8192)] == ["persist"] * 3 and A.default_path(4, 2000, formulation=1) == "persist"
+    assert A.default_path(4096, 201, scheme=2) == "dense"
     assert A.default_path(1, 2000) == "dense"
     monkeypatch.setenv("ASCENT_SMALL_BATCH", "off")
     assert A.default_path(1, 2000) == "persist"
