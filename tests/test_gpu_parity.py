@@ -470,7 +470,7 @@ def _check_against_oracle_samples(coracle, S, r, idx, tol=1e-9):
 
 def test_config4_shard_default_dispatch(coracle, monkeypatch):
     """BASELINE.json configs[3]: one contiguous 32 768-NLP shard of the 262 144-problem config-4 box (what each of
-    the 8 GPUs solves), through the DEFAULT dispatch -- at this size the fused k_solve kernel.  Every problem
+    the 8 GPUs solves), through the DEFAULT dispatch -- the persistent kernel at every size since round 2 (round 1: the fused k_solve).  Every problem
     converges; 64 spread samples equal the oracle (same iteration counts, t_f to 1e-9)."""
     monkeypatch.delenv("ASCENT_PIPELINE", raising=False)
     monkeypatch.delenv("ASCENT_FACTOR", raising=False)
