@@ -22,6 +22,15 @@
 // Backward Euler (the reference's NODES=2; p_solve<0,0>), the trapezoid (<1,0>) and the v1 formulation (<0,1>).
 #include <hip/hip_runtime.h>
 
+// Floating-point contraction within a statement only (the front end's choice, the same in every inlined copy of a function).
+// The kernel below evaluates the Jacobian blocks of a node again in every phase instead of storing them; with the default
+// (contraction across statements, decided per copy by the back end) two copies of the SAME expression may round
+// differently, the implicit block A of the factor phase is then not bit for bit the A of the forward and adjoint phases, and
+// near the solution -- where the eliminated terminal slacks put sigma = z/s ~ 1e12 on the velocity rows -- that 1e-16 becomes
+// 1e-8 in the multiplier steps: a floor of a few 1e-9 under the dual infeasibility (seen with the trapezoid: stragglers at
+// tol 1e-9, failures at 1e-10).  Costs nothing measurable (4.19 ms either way for the config-3 batch).
+#pragma clang fp contract(on)
+
 #include <cstdio>
 #include <cstdlib>
 
@@ -575,6 +584,13 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             nu_pen = 1.0;
           }
         }
+#ifdef PERSIST_TRACE      // diagnostic build: the iteration history of one NLP (scripts/persist_trace.py)
+        if (role == 0 && p == PERSIST_TRACE && K > 100)
+          printf("[persist] K=%d iter %2d mu %.1e E0 %.2e (dual %.1e primal %.1e compl %.1e..%.1e s_d %.2g) alpha %.3g adu %.3g ls %d dw %.1e nu_pen %.2g c1 %.2e\n", K, (int)iters, mu,
+                 e.err(0.0), e.rd, e.cinf, e.pmin, e.pmax, e.sd, alpha, adu, (int)sc[X_LS], sc[X_DWL], nu_pen, c1);
+        if (role == 0 && p == PERSIST_TRACE && K > 100)
+          printf("[persist]      dual rows: nodes %.2e | th %.2e s1 %.2e s2 %.2e\n", rd, fabs(rth - stt.zlt + stt.zut), fabs(-stt.nu1 - stt.zs1), fabs(-stt.nu2 - stt.zs2));
+#endif
         wsync();
         if (role == 0) {
           put_scal(sc, X_S, stt);

@@ -440,6 +440,7 @@ static double barrier(const oder *d, const iter_t *it, double mu) {
 }
 
 static double g_err_rd, g_err_cc, g_err_comp, g_err_sd;     /* the pieces of the last kkt_error (trace only) */
+static double g_err_rt[11];                                  /* ... its dual part by row type: x y xdot ydot angle angledot mass u | theta s1 s2 */
 /* optimality error E_mu (Waechter & Biegler eq. 5) */
 static double kkt_error(const oder *d, work_t *w, const iter_t *it, double mu) {
   int K = w->K; double hT = w->h * d->T, th = it->sc[S_TH], dt = hT * th;
@@ -466,7 +467,11 @@ static double kkt_error(const oder *d, work_t *w, const iter_t *it, double mu) {
     }
     for (int i = 0; i < 7; i++) rd = fmax(rd, fabs(r[i]));
     double u = it->u[k];
-    rd = fmax(rd, fabs((g_form == 1 ? -0.5 * d->aub * l[IA] : -dt * d->alpha * l[IW]) - zb[4] + zb[5]));
+    const double ru = (g_form == 1 ? -0.5 * d->aub * l[IA] : -dt * d->alpha * l[IW]) - zb[4] + zb[5];
+    rd = fmax(rd, fabs(ru));
+    if (k == 0) memset(g_err_rt, 0, sizeof g_err_rt);
+    for (int i = 0; i < 7; i++) g_err_rt[i] = fmax(g_err_rt[i], fabs(r[i]));
+    g_err_rt[7] = fmax(g_err_rt[7], fabs(ru));
     double lo[3] = {z[IA], z[IM], u + 1.0}, up[3] = {d->aub - z[IA], 1.0 - z[IM], 1.0 - u};
     for (int b = 0; b < 3; b++) {
       comp = fmax(comp, fmax(fabs(lo[b] * zb[2 * b] - mu), fabs(up[b] * zb[2 * b + 1] - mu)));
@@ -475,6 +480,7 @@ static double kkt_error(const oder *d, work_t *w, const iter_t *it, double mu) {
   }
   rd = fmax(rd, fabs(rth - it->sc[S_ZLT] + it->sc[S_ZUT]));
   rd = fmax(rd, fmax(fabs(-it->sc[S_NU1] - it->sc[S_ZS1]), fabs(-it->sc[S_NU2] - it->sc[S_ZS2])));
+  g_err_rt[8] = fabs(rth - it->sc[S_ZLT] + it->sc[S_ZUT]); g_err_rt[9] = fabs(-it->sc[S_NU1] - it->sc[S_ZS1]); g_err_rt[10] = fabs(-it->sc[S_NU2] - it->sc[S_ZS2]);
   comp = fmax(comp, fmax(fabs((th - d->tlb) * it->sc[S_ZLT] - mu), fabs((d->tub - th) * it->sc[S_ZUT] - mu)));
   comp = fmax(comp, fmax(fabs(it->sc[S_S1] * it->sc[S_ZS1] - mu), fabs(it->sc[S_S2] * it->sc[S_ZS2] - mu)));
   l1 += fabs(it->sc[S_NU3]) + fabs(it->sc[S_NU1]) + fabs(it->sc[S_NU2]);
@@ -549,6 +555,7 @@ static int solve_one(const oparams *prm, int nt, int max_iter, double tol, int w
   for (int iter = 0; iter < max_iter; iter++) {
     double e0 = kkt_error(&d, w, &it, 0.0);
     const double t_rd = g_err_rd, t_cc = g_err_cc, t_comp = g_err_comp, t_sd = g_err_sd;
+    double t_rt[11]; memcpy(t_rt, g_err_rt, sizeof t_rt);
     if (e0 <= tol) { status = ST_CONVERGED; break; }
     while (mu > tol / 10.0 && kkt_error(&d, w, &it, mu) <= g_keps * mu) {
       mu = fmax(tol / 10.0, fmin(g_kmu * mu, pow(mu, g_thmu)));
@@ -608,6 +615,8 @@ static int solve_one(const oparams *prm, int nt, int max_iter, double tol, int w
     if (!ok) { status = ST_LINESEARCH; break; }
     if (g_trace) fprintf(stderr, "[oracle] K=%d iter %2d mu %.1e E0 %.2e (dual %.1e primal %.1e compl %.1e s_d %.2g) Emu %.2e alpha %.3g (apr %.3g) adu %.3g dw %.1e nu_pen %.2g c1 %.2e\n", K, iter, mu, e0,
                          t_rd, t_cc, t_comp, t_sd, kkt_error(&d, w, &it, mu), alpha, apr, adu, dw, nu_pen, c1);
+    if (g_trace) fprintf(stderr, "[oracle]       dual rows: x %.2e y %.2e vx %.2e vy %.2e a %.2e w %.2e m %.2e u %.2e | th %.2e s1 %.2e s2 %.2e\n", t_rt[0], t_rt[1], t_rt[2],
+                         t_rt[3], t_rt[4], t_rt[5], t_rt[6], t_rt[7], t_rt[8], t_rt[9], t_rt[10]);
     for (int i = 0; i < 8 * K; i++) blob[i] += alpha * w->step[i];
     for (int i = 0; i < 7 * K; i++) it.lam[i] += alpha * st.lam[i];
     for (int i = 0; i < 6 * K; i++) it.zb[i] += adu * st.zb[i];

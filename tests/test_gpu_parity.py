@@ -607,6 +607,47 @@ def test_persistent_kernel_trapezoid_matches_split_pipeline_and_oracle(coracle, 
     assert r.status[0] == 0 and abs(r.final_time()[0] - 435.22714) < 1e-4          # SURVEY Appendix C's independent trapezoid probe: 435.22715 s
 
 
+def test_persistent_kernel_tight_tolerances_on_the_config4_box(coracle):
+    """The persistent kernel evaluates the Jacobian blocks of a node again in every phase; the phases must see the same bits
+    (floating-point contraction is pinned to the statement level in ascent_persist.hip).  A 1e-16 difference between the
+    implicit block of the factor phase and that of the sweeps is multiplied by sigma = z/s ~ 1e12 of the eliminated terminal
+    slacks: before the pin the trapezoid needed up to 58 iterations where the oracle needs 28 at tol 1e-9 and ran into
+    max_iter at 1e-10.  64 NLPs across BASELINE config 4's box, both schemes: iteration counts of the oracle (equal at
+    1e-9, within 2 at 1e-10), every NLP converged."""
+    S = A.sweep_config4()[::4099][:64]
+    for scheme in (0, 1):
+        for tol, slack in ((1e-9, 0), (1e-10, 2)):
+            r = A.solve_batch(S, 200, tol=tol, scheme=scheme, max_iter=500)
+            ref = coracle.solve_batch(S, 200, 500, tol, scheme=scheme)
+            coracle.set_scheme(0)
+            assert np.all(r.status == 0) and np.all(ref["status"] == 0)
+            assert np.abs(r.iters.astype(int) - ref["iters"]).max() <= slack, (scheme, tol, r.iters, ref["iters"])
+            assert np.abs(r.tf - ref["tf"]).max() <= 1e-10
+
+
+def test_newton_step_residual_with_inconsistent_slack_multipliers(coracle):
+    """The Newton step of every hand-tuned path at an iterate whose terminal slack multipliers do not match their constraint
+    multipliers (what a truncated dual step leaves behind: nu_i + z_i != 0), against the generic sparse LU: the multiplier
+    steps of the terminal inequalities (sigma ~ 1e12 there) and of the defects.  This is the iterate at which the persistent
+    kernel's trapezoid lost four digits before its phases were made to evaluate bit-identical blocks."""
+    from conftest import generic_lu_newton_step, params_of_row
+    S = A.sweep_config4()[::4099][:64]
+    nt, K = 200, 199
+    for scheme in (0, 1):
+        sol = coracle.solve_batch(S[42:43], nt, 500, 1e-8, want_blob=True, scheme=scheme)
+        coracle.set_scheme(0)
+        blob = sol["blob"][0].copy()
+        blob[21 * K + 5] *= 0.9
+        blob[21 * K + 6] *= 0.9
+        lu = generic_lu_newton_step(params_of_row(S[42]), nt, blob, 1e-9, 0.0, scheme)[0]
+        for path in ("persist", "split_wide", "split_lane"):
+            step = A.kkt_step(S[42:43], blob[:, None], 1e-9, 0.0, nt, path=path, scheme=scheme)[0][:, 0]
+            for j in (5, 6, 8, 9):        # d zs1, d zs2, d nu1, d nu2: 1e-10 of the multipliers themselves (z_s2 ~ 30; before the pin: 1.6e-8)
+                assert abs(step[21 * K + j] - lu[21 * K + j]) <= 1e-10 * max(1.0, abs(blob[21 * K + 6])), (scheme, path, j)
+            dl = np.abs(step[8 * K:15 * K] - lu[8 * K:15 * K]).max()
+            assert dl <= 1e-9, (scheme, path, dl)                  # (before the pin: 2.1e-8)
+
+
 def test_persistent_kernel_v1_formulation_matches_split_pipeline_and_oracle(coracle, monkeypatch):
     """formulation 1 (the v1 script of the PDF appendix: the angle itself is the MV, an algebraic row without coupling to the
     previous step) through the persistent kernel: identical iteration counts and t_f to rounding against the split pipeline and
