@@ -43,7 +43,7 @@ typedef struct ascent_params {
   double angle_ub;     /* :94  upper bound of angle (= physical/3), pi/3                */
   double tf_lb;        /* :39                                                            */
   double tf_ub;        /* :39                                                            */
-  double dcost;        /* :99  MV movement penalty (accepted)             */
+  double dcost;        /* :99  MV movement penalty (applied with ascent_opts.move_penalty = 1) */
 } ascent_params;
 
 typedef struct ascent_opts {
@@ -76,6 +76,13 @@ typedef struct ascent_opts {
                                ascent_coast_batch's coast arc ends at its apoapsis                          */
   int32_t solver_path;  /* 0 = automatic (hand-tuned sparse kernels for schemes 0/1, dense-block path for scheme 2);
                            ASCENT_PATH_DENSE = the dense-block path for any scheme (formulation 0 only)       */
+  int32_t move_penalty; /* 0 = ascent_params.dcost is ignored (the default: the penalty moves the reference's t_f by 3.5e-6
+                               relative);
+                           1 = :99 angledoubledot.DCOST applied: the objective is tf + dcost * sum_k |u_k - u_{k-1}|
+                               (u_{-1} = 0, the MV's initial value; an l1 term with a slack pair per step, as APMonitor
+                               documents DCOST).  Any scheme, formulation 0; carried by the dense-block path (the control
+                               becomes the eighth state of a stage), Riccati form                                   */
+  int32_t reserved;     /* 0 */
 } ascent_opts;
 
 enum ascent_status {           /* function return codes */

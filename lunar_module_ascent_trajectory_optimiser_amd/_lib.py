@@ -27,7 +27,7 @@ class AscentOptsC(C.Structure):
     _fields_ = [("n_nodes", C.c_int32), ("scheme", C.c_int32), ("max_iter", C.c_int32),
                 ("warm_start", C.c_int32), ("tol", C.c_double), ("mu_init", C.c_double),
                 ("formulation", C.c_int32), ("coarse_nodes", C.c_int32), ("terminal", C.c_int32),
-                ("solver_path", C.c_int32)]
+                ("solver_path", C.c_int32), ("move_penalty", C.c_int32), ("reserved", C.c_int32)]
 
 
 SYMBOLS = ("ascent_version", "ascent_device_count", "ascent_strerror", "ascent_solve_batch",

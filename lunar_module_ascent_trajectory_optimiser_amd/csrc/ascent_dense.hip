@@ -38,11 +38,22 @@ using namespace ascent;
 namespace {
 
 // ---- per-NLP workspace (doubles), all node arrays [row][K] with the step index contiguous ----------------------
-constexpr int NIT = 21;                       // rows of an iterate / step: z[7] u lambda[7] zb[6]
+constexpr int NIT = 26;                       // rows of an iterate / step: z[7] u lambda[7] zb[6] | move penalty: lambda_u p n z_p z_n
 constexpr int O_Z = 0, O_U = 7, O_L = 8, O_ZB = 15;
-constexpr int NV_GA = 0, NV_GB = 7, NV_P = 14, NNV = 24;   // node vectors: Ja'lambda, Jb'lambda, partials[10]
+constexpr int O_LU = 21, O_PP = 22, O_PN = 23, O_ZP = 24, O_ZN = 25;    // (used with DGeo::dc only, see "move penalty" below)
+constexpr int NV_GA = 0, NV_GB = 8, NV_P = 16, NNV = 27;   // node vectors: Ja'lambda[8], Jb'lambda[8], partials[11]
 // partials written by d_eval: 0 c1 (sum |c|)  1 cinf  2 sum of logs  3 pmin  4 pmax  5 zsum  6 l1  7 J_theta'lambda
-//                             8 H_u,theta  9 H_theta,theta
+//                             8 H_u,theta  9 H_theta,theta  10 dcost (p + n)
+//
+// Move penalty (ascent_opts.move_penalty = 1; the reference's angledoubledot.DCOST = 1e-5, LO:99): the objective gains
+// dcost * sum_k |u_k - u_{k-1}|, u_{-1} = 0, as an l1 term with a slack pair per step: u_k - u_{k-1} = p_k - n_k, p, n >= 0,
+// cost dcost (p_k + n_k).  The control of step k then couples to the control of step k-1: u_k becomes the EIGHTH STATE of
+// the stage (the padding slot of the 8x8 blocks: row 7 of the step defect is the movement equation, Ja[7][7] = -1,
+// Jb[7][7] = 1, column 7 of Jb is the old control column, the control's bound terms and its cross derivative with theta move
+// into the state blocks), and the stage's scalar control is delta_k = p_k - n_k, whose two bounded slacks reduce to one
+// pivot: with Sigma_p = z_p/p, Sigma_n = z_n/n and the stationarity residuals r_p = dcost - mu/p - lambda_u,
+// r_n = dcost - mu/n + lambda_u the pair behaves like a control with curvature R = 1/(1/Sigma_p + 1/Sigma_n), gradient
+// g = R (r_p/Sigma_p - r_n/Sigma_n) and control column -e_7.  The Riccati recursion itself does not change.
 constexpr int G_JA = 0, G_JB = 1, G_HAA = 2, G_HAB = 3, G_HBB = 4, G_V = 5, NGRID = 6;    // stage record: 8x8 grids
 // rows of the vector grid G_V:  0 c   1 Ju   2 Jtheta   3 Ha,theta   4 Hb,theta
 constexpr int F_EA = 0, F_LA = 1, F_EL2 = 2, F_GAIN = 3;    // forward record: three 8x8 grids + 16 gains
@@ -58,7 +69,7 @@ enum {  // scalar record
 enum { ST_TRIAL = 0, ST_NEWTON = 1, ST_DONE = 3 };     // ST_NEWTON: waiting for the PCR solve of its Newton system
 
 struct DGeo {
-  int K, scheme, terminal;
+  int K, scheme, terminal, dc;       // dc: the l1 move penalty is on
   __host__ __device__ size_t nlp_doubles() const {
     return (size_t)K * (3 * NIT + NNV + NGRID * 64 + FWD_DOUBLES) + NSCAL;
   }
@@ -151,6 +162,14 @@ __global__ __launch_bounds__(WAVE) void d_init(const ascent_params *params, long
   ASC_UNROLL
   for (int b = 0; b < 6; b++) it[(O_ZB + b) * K + k] = zb[b];
   for (int r = 0; r < NIT; r++) st[r * K + k] = 0.0;
+  if (g.dc) {      // slacks of the movement equation around the guess's own movement; multipliers that zero their stationarity rows
+    double up = (k > 0 && warm) ? guess[(7L * K + k - 1) * batch + p] : 0.0;
+    if (k > 0) up = push_in(up, -1.0, 1.0);
+    const double dl = u - up, eps = warm ? 1e-4 : 1e-2, dc = params[p].dcost;
+    it[O_LU * K + k] = 0.0;
+    it[O_PP * K + k] = fmax(dl, 0.0) + eps; it[O_PN * K + k] = fmax(-dl, 0.0) + eps;
+    it[O_ZP * K + k] = dc; it[O_ZN * K + k] = dc;
+  }
   if (k != K - 1) return;
   double *sc = w + g.off_sc();
   Scal s;
@@ -242,6 +261,21 @@ __global__ __launch_bounds__(WAVE) void d_eval(const ascent_params *params, long
   ASC_UNROLL
   for (int i = 0; i < 7; i++) { in[(O_Z + i) * K + k] = zb[i]; in[(O_L + i) * K + k] = lam[i]; }
   in[O_U * K + k] = u;
+  double lu = 0.0, pp = 1.0, pn = 1.0, zp = 0.0, zn = 0.0, cu = 0.0;
+  if (g.dc) {
+    const double up = k ? ic[O_U * K + k - 1] + alpha * st[O_U * K + k - 1] : 0.0;
+    lu = ic[O_LU * K + k] + alpha * st[O_LU * K + k];
+    pp = ic[O_PP * K + k] + alpha * st[O_PP * K + k];
+    pn = ic[O_PN * K + k] + alpha * st[O_PN * K + k];
+    zp = ic[O_ZP * K + k]; zn = ic[O_ZN * K + k];
+    if (!first) {
+      const double ip = rcp(pp), in_ = rcp(pn);
+      zp = fmin(fmax(zp + adu * st[O_ZP * K + k], mlo * ip), mhi * ip);
+      zn = fmin(fmax(zn + adu * st[O_ZN * K + k], mlo * in_), mhi * in_);
+    }
+    in[O_LU * K + k] = lu; in[O_PP * K + k] = pp; in[O_PN * K + k] = pn; in[O_ZP * K + k] = zp; in[O_ZN * K + k] = zn;
+    cu = u - up - pp + pn;
+  }
   if (k == K - 1) store_scal(sc, X_T, stt);
   // ---- the three evaluation points --------------------------------------------------------------------------------
   double Ga[8], Gb[8], Gm[8], Hw[10], fa[7], fb[7], fm[7], zm[7], ax, ay;
@@ -327,6 +361,7 @@ __global__ __launch_bounds__(WAVE) void d_eval(const ascent_params *params, long
   (void)t7b;
   const double Hthth = -2.0 * hT * wm * gmm - sm * mHm;
   const double Huth = -hT * d.alpha * lam[IW];
+  if (g.dc) { c1 += fabs(cu); cinf = fmax(cinf, fabs(cu)); }
   // ---- stage record: 8x8 grids, element (i,j) at [i*8+j] ------------------------------------------------------------
   // Ja = -I - sa Fa - sm Fm Ma ; Jb = I - sb Fb - sm Fm Mb : row by row (F has three unit entries and the 2x4 block G)
   auto frow = [&](const double *G, int r, double *row) __attribute__((always_inline)) {      // row r of F = df/dz
@@ -363,8 +398,10 @@ __global__ __launch_bounds__(WAVE) void d_eval(const ascent_params *params, long
         jb[j] = (j == r ? 1.0 : 0.0) - sb * frb[j] - sm * fmmb[j];
       }
     } else {
-      jb[7] = 1.0;          // the padding slot: x8_k = 0
+      jb[7] = 1.0;          // the padding slot: x8_k = 0; with the move penalty: u_k - u_{k-1} - p_k + n_k
+      if (g.dc) ja[7] = -1.0;
     }
+    if (g.dc && r == IW) jb[7] = -dt * d.alpha;       // the control is a state: its column of the step Jacobian
     ASC_UNROLL
     for (int j = 0; j < 8; j++) { rec[G_JA * 64 + r * 8 + j] = ja[j]; rec[G_JB * 64 + r * 8 + j] = jb[j]; }
   }
@@ -391,16 +428,18 @@ __global__ __launch_bounds__(WAVE) void d_eval(const ascent_params *params, long
   }
   ASC_UNROLL
   for (int j = 0; j < 8; j++) {
-    rec[G_V * 64 + 0 * 8 + j] = j < 7 ? c[j] : 0.0;
-    rec[G_V * 64 + 1 * 8 + j] = j == IW ? -dt * d.alpha : 0.0;
+    rec[G_V * 64 + 0 * 8 + j] = j < 7 ? c[j] : cu;
+    rec[G_V * 64 + 1 * 8 + j] = g.dc ? (j == 7 ? -1.0 : 0.0) : (j == IW ? -dt * d.alpha : 0.0);
     rec[G_V * 64 + 2 * 8 + j] = j < 7 ? Jth[j] : 0.0;
     rec[G_V * 64 + 3 * 8 + j] = j < 7 ? Hath[j] : 0.0;
-    rec[G_V * 64 + 4 * 8 + j] = j < 7 ? Hbth[j] : 0.0;
+    rec[G_V * 64 + 4 * 8 + j] = j < 7 ? Hbth[j] : (g.dc ? Huth : 0.0);
     rec[G_V * 64 + 5 * 8 + j] = 0.0; rec[G_V * 64 + 6 * 8 + j] = 0.0; rec[G_V * 64 + 7 * 8 + j] = 0.0;
   }
   // ---- node vectors and partials ----------------------------------------------------------------------------------
   ASC_UNROLL
   for (int i = 0; i < 7; i++) { nv[(NV_GA + i) * K + k] = ga[i]; nv[(NV_GB + i) * K + k] = gb[i]; }
+  nv[(NV_GA + 7) * K + k] = -lu;                                  // Ja'lambda, Jb'lambda of the control slot
+  nv[(NV_GB + 7) * K + k] = lu - dt * d.alpha * lam[IW];
   double pmin = 1e300, pmax = -1e300, zsum = 0.0, l1 = 0.0;
   ASC_UNROLL
   for (int b = 0; b < 6; b++) { const double pr = dist[b] * zbd[b]; pmin = fmin(pmin, pr); pmax = fmax(pmax, pr); zsum += zbd[b]; }
@@ -408,6 +447,11 @@ __global__ __launch_bounds__(WAVE) void d_eval(const ascent_params *params, long
   for (int i = 0; i < 7; i++) l1 += fabs(lam[i]);
   const double pa = dist[0] * dist[1], pm = dist[2] * dist[3], pu = dist[4] * dist[5];
   double sl = (pa > 0.0 && pm > 0.0 && pu > 0.0) ? log(pa * pm * pu) : NAN;
+  if (g.dc) {
+    pmin = fmin(pmin, fmin(pp * zp, pn * zn)); pmax = fmax(pmax, fmax(pp * zp, pn * zn));
+    zsum += zp + zn; l1 += fabs(lu);
+    sl += (pp > 0.0 && pn > 0.0) ? log(pp * pn) : NAN;
+  }
   if (k == K - 1) {
     const Terminal t = terminal_eval(d, zb);
     const double e1 = fabs(t.e3), e2 = fabs(t.g1 - stt.s1), e3 = fabs(t.g2 - stt.s2);
@@ -418,7 +462,8 @@ __global__ __launch_bounds__(WAVE) void d_eval(const ascent_params *params, long
   }
   nv[(NV_P + 0) * K + k] = c1; nv[(NV_P + 1) * K + k] = cinf; nv[(NV_P + 2) * K + k] = sl; nv[(NV_P + 3) * K + k] = pmin;
   nv[(NV_P + 4) * K + k] = pmax; nv[(NV_P + 5) * K + k] = zsum; nv[(NV_P + 6) * K + k] = l1; nv[(NV_P + 7) * K + k] = rth;
-  nv[(NV_P + 8) * K + k] = Huth; nv[(NV_P + 9) * K + k] = Hthth;
+  nv[(NV_P + 8) * K + k] = g.dc ? 0.0 : Huth; nv[(NV_P + 9) * K + k] = Hthth;
+  nv[(NV_P + 10) * K + k] = g.dc ? params[p].dcost * (pp + pn) : 0.0;
 }
 
 // ==============================================================================================================
@@ -502,6 +547,9 @@ struct Border { double Oth, Otn, Onn, oth, onu; };     // Omega (2x2 symmetric) 
 
 // MODE 0: decisions + Riccati solve + step (the whole Newton iteration).  MODE 1: decisions only; an NLP that needs a Newton
 // step is handed to the PCR kernels (pc_assemble -> ascent_blocktri's cyclic reduction -> pc_step) in state ST_NEWTON.
+#ifdef DENSE_TRACE
+ASC_DEV double s0th_dbg(const double *sc) { return sc[X_S + S_TH]; }
+#endif
 template <int MODE>
 __global__ __launch_bounds__(WAVE) void d_newton(const ascent_params *params, long batch, DGeo g, double *ws, int max_iter,
                                                  double tol, int probe, const double *probe_dw, int *counters) {
@@ -517,19 +565,25 @@ __global__ __launch_bounds__(WAVE) void d_newton(const ascent_params *params, lo
   double mu = sc[X_MU], nu_pen = sc[X_NUP];
   int cur = (int)sc[X_CUR];
   // ---- reduce the partials of the trial point (lane = step, strided) -----------------------------------------------
-  double c1 = 0.0, cinf = 0.0, sl = 0.0, pmin = 1e300, pmax = -1e300, zsum = 0.0, l1 = 0.0, rth = 0.0;
+  double c1 = 0.0, cinf = 0.0, sl = 0.0, pmin = 1e300, pmax = -1e300, zsum = 0.0, l1 = 0.0, rth = 0.0, mv = 0.0;
   for (int k = l; k < K; k += WAVE) {
     c1 += nv[(NV_P + 0) * K + k]; cinf = fmax(cinf, nv[(NV_P + 1) * K + k]); sl += nv[(NV_P + 2) * K + k];
     pmin = fmin(pmin, nv[(NV_P + 3) * K + k]); pmax = fmax(pmax, nv[(NV_P + 4) * K + k]);
     zsum += nv[(NV_P + 5) * K + k]; l1 += nv[(NV_P + 6) * K + k]; rth += nv[(NV_P + 7) * K + k];
+    mv += nv[(NV_P + 10) * K + k];
   }
   c1 = wsum(c1); cinf = wmax(cinf); sl = wsum(sl); pmin = wmin(pmin); pmax = wmax(pmax); zsum = wsum(zsum); l1 = wsum(l1);
   rth = 1.0 + wsum(rth);
+  mv = g.dc ? wsum(mv) : 0.0;                     // the move penalty's part of the objective
+  const double dcw = g.dc ? params[p].dcost : 0.0;
   const Scal stt = load_scal(sc, X_T);
   double iters = sc[X_ITERS];
   if (!first) {     // Armijo test on the l1 merit function
     const double alpha = sc[X_ALPHA], phi0 = sc[X_PHI0], Dm = sc[X_DM];
-    const double phit = stt.th - mu * sl + nu_pen * c1;
+    const double phit = (stt.th + mv) - mu * sl + nu_pen * c1;
+#ifdef DENSE_TRACE
+    if (l == 0 && p == 0) printf("[dense] K=%d it %d ls %d alpha %.3g: phit-phi0 %.3e (th %.3e mv %.3e) alpha*Dm %.3e c1 %.3e nu %.3g mu %.1e\n", K, (int)iters, (int)sc[X_LS], alpha, phit - phi0, stt.th - s0th_dbg(sc), mv, alpha * Dm, c1, nu_pen, mu);
+#endif
     if (!(isfinite(phit) && phit <= phi0 + 1e-8 * alpha * Dm + 2.220446049250313e-15 * fabs(phi0))) {
       const int ls = (int)sc[X_LS] + 1;
       if (l == 0) {
@@ -563,7 +617,13 @@ __global__ __launch_bounds__(WAVE) void d_newton(const ascent_params *params, lo
     ASC_UNROLL
     for (int q = 0; q < 7; q++) rd = fmax(rd, fabs(r[q]));
     const double dt = (1.0 / K) * d.T * s.th;
-    rd = fmax(rd, fabs(-dt * d.alpha * it[(O_L + IW) * K + k] - it[(O_ZB + 4) * K + k] + it[(O_ZB + 5) * K + k]));
+    if (g.dc) {      // the control's row carries the multipliers of its two movement equations; rows of the slack pair
+      const double r7 = nv[(NV_GB + 7) * K + k] + (k + 1 < K ? nv[(NV_GA + 7) * K + k + 1] : 0.0);
+      rd = fmax(rd, fabs(r7 - it[(O_ZB + 4) * K + k] + it[(O_ZB + 5) * K + k]));
+      rd = fmax(rd, fmax(fabs(dcw - it[O_LU * K + k] - it[O_ZP * K + k]), fabs(dcw + it[O_LU * K + k] - it[O_ZN * K + k])));
+    } else {
+      rd = fmax(rd, fabs(-dt * d.alpha * it[(O_L + IW) * K + k] - it[(O_ZB + 4) * K + k] + it[(O_ZB + 5) * K + k]));
+    }
   }
   rd = wmax(rd);
   ErrParts e;
@@ -578,12 +638,15 @@ __global__ __launch_bounds__(WAVE) void d_newton(const ascent_params *params, lo
   e.pmin = pmin; e.pmax = pmax;
   l1 += fabs(s.nu3) + fabs(s.nu1) + fabs(s.nu2);
   zsum += s.zlt + s.zut + s.zs1 + s.zs2;
-  e.sd = fmax(100.0, (l1 + zsum) / (double)(13 * K + 7)) * 0.01;
+  e.sd = fmax(100.0, (l1 + zsum) / (double)((g.dc ? 16 : 13) * K + 7)) * 0.01;
   if (l == 0) {
     store_scal(sc, X_S, s);
     sc[X_CUR] = cur; sc[X_FIRST] = 0.0; sc[X_ITERS] = iters; sc[X_LS] = 0.0; sc[X_C1] = c1; sc[X_SL] = sl;
   }
   double dw = 0.0;
+#ifdef DENSE_TRACE
+  if (l == 0 && p == 0) printf("[dense] K=%d accepted it %d: E0 %.3e (dual %.2e primal %.2e compl %.2e..%.2e) mu %.1e th %.10f mv %.3e\n", K, (int)iters, e.err(0.0), e.rd, e.cinf, e.pmin, e.pmax, mu, s.th, mv);
+#endif
   if (!probe) {
     if (e.err(0.0) <= tol) {
       if (l == 0) { sc[X_STATUS] = ASCENT_CONVERGED; sc[X_STATE] = ST_DONE; }
@@ -633,12 +696,13 @@ __global__ __launch_bounds__(WAVE) void d_newton(const ascent_params *params, lo
       const double id0 = rcp(a_), id1 = rcp(d.aub - a_), id2 = rcp(m_), id3 = rcp(1.0 - m_), id4 = rcp(u_ + 1.0), id5 = rcp(1.0 - u_);
       const double siga = it[(O_ZB + 0) * K + k] * id0 + it[(O_ZB + 1) * K + k] * id1;
       const double sigm = it[(O_ZB + 2) * K + k] * id2 + it[(O_ZB + 3) * K + k] * id3;
-      const double sigu = it[(O_ZB + 4) * K + k] * id4 + it[(O_ZB + 5) * K + k] * id5;
-      if (i == j) Fxx += (i == IA ? siga : i == IM ? sigm : 0.0) + dw;
+      double sigu = it[(O_ZB + 4) * K + k] * id4 + it[(O_ZB + 5) * K + k] * id5;
+      if (i == j) Fxx += (i == IA ? siga : i == IM ? sigm : (i == 7 && g.dc) ? sigu : 0.0) + dw;
       // residual of node k (barrier form), row-indexed: r_i in lane (i, *)
-      double rx = i < 7 ? nv[(NV_GB + i) * K + k] + (k + 1 < K ? nv[(NV_GA + i) * K + k + 1] : 0.0) : 0.0;
+      double rx = (i < 7 || g.dc) ? nv[(NV_GB + i) * K + k] + (k + 1 < K ? nv[(NV_GA + i) * K + k + 1] : 0.0) : 0.0;
       if (i == IA) rx += mu * (id1 - id0);
       if (i == IM) rx += mu * (id3 - id2);
+      if (i == 7 && g.dc) rx += mu * (id5 - id4);
       double Fxb_nu = colvec(R, 2);        // F_x,nu3 = Pi_nu3 (+ terminal gradient of r.v), row-indexed
       if (k == K - 1) {
         const double w1 = s.nu1 + sig1 * cg1 + rs1, w2 = s.nu2 + sig2 * cg2 + rs2;
@@ -660,7 +724,14 @@ __global__ __launch_bounds__(WAVE) void d_newton(const ascent_params *params, lo
         rx += rt;
         Fxb_nu += e3;
       }
-      const double ru = -dt * d.alpha * it[(O_L + IW) * K + k] + mu * (id5 - id4);     // Ju'lambda + barrier gradient
+      double ru = -dt * d.alpha * it[(O_L + IW) * K + k] + mu * (id5 - id4);     // Ju'lambda + barrier gradient
+      if (g.dc) {      // the stage's control is delta = p - n: curvature and gradient of the reduced slack pair
+        const double pp = it[O_PP * K + k], pn = it[O_PN * K + k], lu = it[O_LU * K + k];
+        const double ip = rcp(pp), in_ = rcp(pn);
+        const double isp = rcp(it[O_ZP * K + k] * ip + dw), isn = rcp(it[O_ZN * K + k] * in_ + dw);
+        sigu = rcp(isp + isn);
+        ru = sigu * ((dcw - mu * ip - lu) * isp - (dcw - mu * in_ + lu) * isn);
+      }
       const double Huth = nv[(NV_P + 8) * K + k], Hthth = nv[(NV_P + 9) * K + k];
       // vectors of the record, row-indexed (component i in lane (i,*))
       const double cvec = rowvec_t(V, 0), Ju = rowvec_t(V, 1), Jth = rowvec_t(V, 2), Hath = rowvec_t(V, 3), Hbth = rowvec_t(V, 4);
@@ -683,7 +754,7 @@ __global__ __launch_bounds__(WAVE) void d_newton(const ascent_params *params, lo
       // scalar rows of G for y in (u, theta, nu):  Y' L2  and  Y' E2  with Y = [Ju | Jth | Fxb_th | Fxb_nu]
       const double Y = j == 0 ? Ju : j == 1 ? Jth : j == 2 ? Fxb_th : j == 3 ? Fxb_nu : 0.0;
       const double YL = mm<true>(L, Y, L2), YE = mm<true>(L, Y, E2);
-      const double Guu = sigu + dw + pick(YL, 0, 0);
+      const double Guu = sigu + (g.dc ? 0.0 : dw) + pick(YL, 0, 0);
       const double Guth = Huth + pick(YL, 0, 1), Gunu = pick(YL, 0, 2), gu = ru + pick(YL, 0, 3);
       const double Gthth = Hthth + B.Oth - pick(YE, 2, 1) + pick(YL, 1, 1);
       const double Gthnu = B.Otn + pick(YL, 1, 2);
@@ -742,7 +813,7 @@ __global__ __launch_bounds__(WAVE) void d_newton(const ascent_params *params, lo
   const double tau = fmax(0.99, 1.0 - mu);
   double *st = w + g.off_st();
   double xi = 0.0;                     // dz_{k-1}, column-indexed (component j in lane (*, j))
-  double rmax = 0.0, gsum = 0.0, adu = 1.0, cl = 0.0, dzK = 0.0;
+  double rmax = 0.0, gsum = 0.0, adu = 1.0, cl = 0.0, dzK = 0.0, gmove = 0.0;
   for (int k = 0; k < K; k++) {
     const double *fw = fwd0 + (size_t)k * FWD_DOUBLES;
     const double Ea = fw[F_EA * 64 + l], La = fw[F_LA * 64 + l], EL2 = fw[F_EL2 * 64 + l];
@@ -754,16 +825,39 @@ __global__ __launch_bounds__(WAVE) void d_newton(const ascent_params *params, lo
     const double dz = -(rowsum(Ea * xi) + rowsum(EL2 * yv));        // row-indexed: dz_i in lane (i,*)
     const double dl = rowsum(La * xi) + rowsum(EL2 * yl);
     if (j == 0 && i < 7) { st[(O_Z + i) * K + k] = dz; st[(O_L + i) * K + k] = dl; }
-    if (l == 0) st[O_U * K + k] = du;
+    double du_ = du;                     // the step of the control: the stage's control, or the eighth state
+    if (g.dc) {
+      const double dlu = pick(dl, 7, 0);
+      du_ = pick(dz, 7, 0);
+      const double pp = it[O_PP * K + k], pn = it[O_PN * K + k], zp = it[O_ZP * K + k], zn = it[O_ZN * K + k], lu = it[O_LU * K + k];
+      const double ip = rcp(pp), in_ = rcp(pn);
+      // the slack with the larger curvature from its own row (well conditioned), the other from delta = p - n (its own row
+      // divides a difference of two nearly equal numbers by a curvature that vanishes for an inactive slack)
+      const double sgp = zp * ip + dw, sgn_ = zn * in_ + dw;
+      double dpp, dpn;
+      if (sgp >= sgn_) { dpp = (dlu - (dcw - mu * ip - lu)) * rcp(sgp); dpn = dpp - du; }
+      else { dpn = (-dlu - (dcw - mu * in_ + lu)) * rcp(sgn_); dpp = du + dpn; }
+      const double dzp = ip * (mu - zp * dpp) - zp, dzn = in_ * (mu - zn * dpn) - zn;
+      ASC_FTBR(rmax, ip, dpp); ASC_FTBR(rmax, in_, dpn);
+      ASC_FTB(adu, zp, dzp); ASC_FTB(adu, zn, dzn);
+      gsum -= dpp * ip + dpn * in_;
+      gmove += dpp + dpn;
+#ifdef DENSE_TRACE
+      if (l == 0 && p == 0 && (fabs(dpp) > 1.0 || fabs(dpn) > 1.0 || fabs(du) > 1.0 || fabs(du_) > 1.0))
+        printf("[dense fwd] k %d ddelta %.3e du %.3e dlu %.3e | pp %.3e pn %.3e zp %.3e zn %.3e lu %.3e | dpp %.3e dpn %.3e | gains th %.3e nu %.3e 0 %.3e dw %.1e\n", k, du, du_, dlu, pp, pn, zp, zn, lu, dpp, dpn, ku_th, ku_nu, ku_0, dw);
+#endif
+      if (l == 0) { st[O_LU * K + k] = dlu; st[O_PP * K + k] = dpp; st[O_PN * K + k] = dpn; st[O_ZP * K + k] = dzp; st[O_ZN * K + k] = dzn; }
+    }
+    if (l == 0) st[O_U * K + k] = du_;
     // bound multipliers and both fraction-to-boundary rules (every lane redundantly)
     const double dza = pick(dz, IA, 0), dzm = pick(dz, IM, 0);
     const double a_ = it[(O_Z + IA) * K + k], m_ = it[(O_Z + IM) * K + k], u_ = it[O_U * K + k];
     const double id[6] = {rcp(a_), rcp(d.aub - a_), rcp(m_), rcp(1.0 - m_), rcp(u_ + 1.0), rcp(1.0 - u_)};
     ASC_FTBR(rmax, id[0], dza); ASC_FTBR(rmax, id[1], -dza);
     ASC_FTBR(rmax, id[2], dzm); ASC_FTBR(rmax, id[3], -dzm);
-    ASC_FTBR(rmax, id[4], du); ASC_FTBR(rmax, id[5], -du);
-    gsum += dza * (id[1] - id[0]) + dzm * (id[3] - id[2]) + du * (id[5] - id[4]);
-    const double dx3[3] = {dza, dzm, du};
+    ASC_FTBR(rmax, id[4], du_); ASC_FTBR(rmax, id[5], -du_);
+    gsum += dza * (id[1] - id[0]) + dzm * (id[3] - id[2]) + du_ * (id[5] - id[4]);
+    const double dx3[3] = {dza, dzm, du_};
     ASC_UNROLL
     for (int b = 0; b < 3; b++) {
       const double zl = it[(O_ZB + 2 * b) * K + k], zu = it[(O_ZB + 2 * b + 1) * K + k];
@@ -775,7 +869,7 @@ __global__ __launch_bounds__(WAVE) void d_newton(const ascent_params *params, lo
     // c'(lambda + dlambda) for the curvature estimate of the merit function
     const double V = (w + g.off_rec() + (size_t)k * NGRID * 64)[G_V * 64 + l];
     const double cvec = rowvec_t(V, 0);
-    const double lam_i = i < 7 ? it[(O_L + i) * K + k] : 0.0;
+    const double lam_i = i < 7 ? it[(O_L + i) * K + k] : g.dc ? it[O_LU * K + k] : 0.0;
     cl += j == 0 ? cvec * (lam_i + dl) : 0.0;
     xi = __shfl(dz, j << 3);           // next step's xi_j = dz_j
     if (k == K - 1) dzK = dz;
@@ -800,7 +894,7 @@ __global__ __launch_bounds__(WAVE) void d_newton(const ascent_params *params, lo
   ASC_FTB(apr, s.s1, ds.s1); ASC_FTB(apr, s.s2, ds.s2);
   ASC_FTB(adu, s.zlt, ds.zlt); ASC_FTB(adu, s.zut, ds.zut);
   ASC_FTB(adu, s.zs1, ds.zs1); ASC_FTB(adu, s.zs2, ds.zs2);
-  double gd = mu * gsum;
+  double gd = mu * gsum + dcw * gmove;
   gd += ds.th * (1.0 - mu / dl_ + mu / dU) - mu * ds.s1 / s.s1 - mu * ds.s2 / s.s2;
   cl += tm.e3 * (s.nu3 + ds.nu3) + (tm.g1 - s.s1) * (s.nu1 + ds.nu1) + (tm.g2 - s.s2) * (s.nu2 + ds.nu2);
   const double curv = -gd + cl;
@@ -812,7 +906,7 @@ __global__ __launch_bounds__(WAVE) void d_newton(const ascent_params *params, lo
     store_scal(sc, X_D, ds);
     sc[X_MU] = mu; sc[X_NUP] = nu_pen; sc[X_DWL] = dw; sc[X_REFAC] += refac;
     sc[X_DM] = gd - nu_pen * c1;
-    sc[X_PHI0] = s.th - mu * sl + nu_pen * c1;
+    sc[X_PHI0] = (s.th + mv) - mu * sl + nu_pen * c1;
     sc[X_ALPHA] = apr; sc[X_ADU] = adu;
     if (probe) { sc[X_STATE] = ST_DONE; sc[X_STATUS] = 0; }
     else atomicAdd(&counters[0], 1);
@@ -1225,8 +1319,9 @@ static int pcr_newton(const ascent_params *dp, long batch, DGeo g, double *ws, i
 
 int dense_run(const ascent_params *dp, long batch, int K, int scheme, int terminal, double *ws, const double *dguess, int warm,
               int max_iter, double tol, double mu0, double *dtraj, double *dtf, int *dstatus, int *diters, double *dblob,
-              hipStream_t stream, char *err, size_t errlen, int pcr) {
-  DGeo g{K, scheme, terminal};
+              hipStream_t stream, char *err, size_t errlen, int pcr, int move_penalty) {
+  DGeo g{K, scheme, terminal, move_penalty ? 1 : 0};
+  if (g.dc && pcr) { snprintf(err, errlen, "the move penalty is carried by the Riccati form of the dense path only"); return ASCENT_E_ARG; }
   int *counters = (int *)((char *)ws + (size_t)batch * g.nlp_doubles() * sizeof(double));
   static int *host_cnt_dev[64] = {nullptr};
   int dev_ = 0;

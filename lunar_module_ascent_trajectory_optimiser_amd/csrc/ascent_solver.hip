@@ -842,7 +842,10 @@ int hip_fail(hipError_t e, const char *what) {
 // Nested iteration (mesh continuation).  A cold start on a grid of >= 40 nodes first solves the same NLP on a
 // grid of three tenths of the nodes (recursively: 201 -> 60 -> 17), prolongs that primal-dual solution to the next
 // grid and warm-starts the solve there: with mu0 = 1e-6 from the coarsest (cold-started) grid, with mu0 = max(1e-9,
-// tol/100) from a grid that was itself warm-started.  On the config-3 sweep 9 + 4 + 8 iterations on 17 / 59 / 200
+// tol/100) from a grid that was itself warm-started (ASCENT_NESTED_MU=first,next overrides the pair for experiments:
+// scripts/nested_mu_scan.py; DESIGN.md has the scan -- tol/10 and 0.4 tol are 2 % and 7 % faster on the config-3 batch and
+// 30 % at N = 2000, but leave the convergence test on a knife edge often enough that iteration counts differ between kernel
+// families, and with 0.4 tol t_f depends on the start by 40 mu = 1.7e-8).  On the config-3 sweep 9.7 + 4 + 7.7 iterations on 17 / 59 / 200
 // intervals instead of 24 on 200, and hardly any straggler tail (scripts/nested_levels.py compares the policies).  (The CPU
 // restatement under the test tree follows the same rule, constants and arithmetic, so that iteration counts can be
 // compared one to one.)
@@ -921,7 +924,7 @@ __global__ __launch_bounds__(WAVE) void k_terminal_params(const ascent_params *i
 }
 
 bool use_dense_path(const ascent_opts *o, int64_t batch) {
-  if (o->scheme == 2 || o->solver_path == ASCENT_PATH_DENSE) return true;
+  if (o->scheme == 2 || o->solver_path == ASCENT_PATH_DENSE || o->move_penalty) return true;
   const char *e = getenv("ASCENT_PIPELINE");
   if (e) return !strcmp(e, "dense") && o->formulation == 0;
   // A handful of NLPs cannot fill the hand-tuned kernels (one wavefront per four NLPs, serial over the nodes: 2.8 ms at
@@ -1061,7 +1064,8 @@ int check_common(const ascent_params *p, int64_t batch, const ascent_opts *o, in
   if (o->scheme < 0 || o->scheme > 2) { snprintf(g_err, sizeof g_err, "scheme %d not supported (0 = backward Euler, the reference's NODES=2; 1 = trapezoid; 2 = Hermite-Simpson)", o->scheme); return ASCENT_E_ARG; }
   if (o->terminal != 0 && o->terminal != 1) { snprintf(g_err, sizeof g_err, "terminal %d not supported (0 = reference, 1 = ellipse proper)", o->terminal); return ASCENT_E_ARG; }
   if (o->solver_path != ASCENT_PATH_AUTO && o->solver_path != ASCENT_PATH_DENSE) { snprintf(g_err, sizeof g_err, "solver_path must be 0 (automatic) or ASCENT_PATH_DENSE"); return ASCENT_E_ARG; }
-  if ((o->scheme == 2 || o->solver_path == ASCENT_PATH_DENSE) && o->formulation != 0) { snprintf(g_err, sizeof g_err, "the dense-block path (scheme 2 / ASCENT_PATH_DENSE) has formulation 0 only"); return ASCENT_E_ARG; }
+  if ((o->scheme == 2 || o->solver_path == ASCENT_PATH_DENSE || o->move_penalty) && o->formulation != 0) { snprintf(g_err, sizeof g_err, "the dense-block path (scheme 2 / ASCENT_PATH_DENSE / move_penalty) has formulation 0 only"); return ASCENT_E_ARG; }
+  if (o->move_penalty != 0 && o->move_penalty != 1) { snprintf(g_err, sizeof g_err, "move_penalty must be 0 or 1"); return ASCENT_E_ARG; }
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { snprintf(g_err, sizeof g_err, "no HIP device available"); return ASCENT_E_NODEVICE; }
   if (device_id < 0 || device_id >= n || device_id >= MAX_DEV) { snprintf(g_err, sizeof g_err, "device %d of %d", device_id, n); return ASCENT_E_NODEVICE; }
@@ -1088,7 +1092,7 @@ int ascent_debug_profile(unsigned long long *out8, int reset) {
 }
 #endif
 
-int ascent_version(void) { return 200; }
+int ascent_version(void) { return 210; }
 
 int ascent_device_count(void) {
   int n = 0;
@@ -1126,6 +1130,10 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
   if (!tf_out || !status_out || !iters_out) { snprintf(g_err, sizeof g_err, "null output pointer"); return ASCENT_E_ARG; }
   if (o->warm_start < 0 || o->warm_start > 2 || (o->warm_start && !guess)) { snprintf(g_err, sizeof g_err, "warm_start needs a guess blob"); return ASCENT_E_ARG; }
   if (!(o->tol > 0) || o->max_iter < 0) { snprintf(g_err, sizeof g_err, "tol must be > 0, max_iter >= 0"); return ASCENT_E_ARG; }
+  if (o->move_penalty && !ptr_is_device) {      // (device-resident parameter sets are the caller's to check: the weight must be positive)
+    for (int64_t i = 0; i < batch; i++)
+      if (!(p[i].dcost > 0.0)) { snprintf(g_err, sizeof g_err, "move_penalty = 1 needs ascent_params.dcost > 0 (problem %lld has %g)", (long long)i, p[i].dcost); return ASCENT_E_ARG; }
+  }
   std::lock_guard<std::mutex> lock(g_mu[device_id]);
   HIPCHK(hipSetDevice(device_id));
   hipStream_t stream = (hipStream_t)stream_;
@@ -1133,7 +1141,7 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
   const size_t rows = 21 * (size_t)K + NSC;
   const int lpt = lanes_per_tile(batch);
   const bool dense = use_dense_path(o, batch);
-  const bool pcr = dense && use_pcr_newton(batch);
+  const bool pcr = dense && !o->move_penalty && use_pcr_newton(batch);
   const bool persist = !dense && use_persist_path(o, batch);
   const bool split = o->scheme == 1 || o->formulation == 1 || use_split_pipeline(batch);
   // grid levels of the nested iteration, finest first (levels[0] = n_nodes); one level = a plain solve
@@ -1201,9 +1209,11 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
     w.int_n = n3;
   }
   HIPCHK(hipEventRecord(w.ev0, stream));
+  double mu_first = NESTED_MU_FIRST, mu_next = nested_mu_next(o->tol);
+  if (const char *e = getenv("ASCENT_NESTED_MU")) sscanf(e, "%lf,%lf", &mu_first, &mu_next);      // experiments only ("first,next")
   if (persist) {      // all levels inside the kernel's own layout
     rc = persist_run_nested(dp, (long)batch, (int)o->scheme, (int)o->formulation, levels, nlev, w.ws, dguess, (int)o->warm_start, (int)o->max_iter, o->tol,
-                            fmax(o->tol, NESTED_COARSE_TOL), mu0, NESTED_MU_FIRST, nested_mu_next(o->tol), dtraj, dtf, dstatus, diters,
+                            fmax(o->tol, NESTED_COARSE_TOL), mu0, mu_first, mu_next, dtraj, dtf, dstatus, diters,
                             dblob, stream, g_err, sizeof g_err);
     if (rc) return rc;
   }
@@ -1212,13 +1222,13 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
     const bool fin = l == 0, first = l == nlev - 1;
     const double *g_l = first ? dguess : w.gss;
     const int warm_l = first ? (int)o->warm_start : 2;
-    const double mu_l = first ? mu0 : (l == nlev - 2 ? NESTED_MU_FIRST : nested_mu_next(o->tol));
+    const double mu_l = first ? mu0 : (l == nlev - 2 ? mu_first : mu_next);
     const double tol_l = fin ? o->tol : fmax(o->tol, NESTED_COARSE_TOL);
     double *traj_l = fin ? dtraj : nullptr, *tf_l = fin ? dtf : w.tfc, *blob_l = fin ? dblob : w.sol;
     int *st_l = fin ? dstatus : w.st_c, *it_l = fin ? diters : w.it_c;
     if (dense) {
       rc = dense_run(dp, (long)batch, Kl, (int)o->scheme, 0, w.ws, g_l, warm_l, (int)o->max_iter, tol_l, mu_l, traj_l, tf_l, st_l,
-                     it_l, blob_l, stream, g_err, sizeof g_err, pcr ? 1 : 0);
+                     it_l, blob_l, stream, g_err, sizeof g_err, pcr ? 1 : 0, (int)o->move_penalty);
       if (rc) return rc;
     } else if (split) {
       rc = pipeline_run(dp, (long)batch, Kl, (int)o->scheme, (int)o->formulation, w.ws, g_l, warm_l, (int)o->max_iter, tol_l, mu_l,

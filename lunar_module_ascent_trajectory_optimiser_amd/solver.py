@@ -26,7 +26,7 @@ TERMINALS = {"reference": 0, "ellipse": 1}
 FORMULATIONS = {"current": 0, "v1": 1}
 
 
-def _opts(nt, max_iter, tol, warm_start, mu_init, scheme=0, formulation=0, coarse_nodes=0, terminal=0, path="auto"):
+def _opts(nt, max_iter, tol, warm_start, mu_init, scheme=0, formulation=0, coarse_nodes=0, terminal=0, path="auto", move_penalty=False):
     scheme = SCHEMES.get(scheme, scheme)
     formulation = FORMULATIONS.get(formulation, formulation)
     terminal = TERMINALS.get(terminal, terminal)
@@ -34,7 +34,7 @@ def _opts(nt, max_iter, tol, warm_start, mu_init, scheme=0, formulation=0, coars
         raise ValueError('solver path must be "auto" or "dense"')
     return _lib.AscentOptsC(n_nodes=nt, scheme=int(scheme), max_iter=max_iter, warm_start=warm_start, tol=tol,
                             mu_init=mu_init, formulation=int(formulation), coarse_nodes=int(coarse_nodes),
-                            terminal=int(terminal), solver_path=_lib.PATHS[path])
+                            terminal=int(terminal), solver_path=_lib.PATHS[path], move_penalty=int(bool(move_penalty)), reserved=0)
 
 
 def _ptr(a):
@@ -110,7 +110,7 @@ class BatchResult:
 def solve_batch(params, nt: int = 200, tol: float = 1e-9, max_iter: int = 300, guess: np.ndarray | None = None,
                 warm_start: int | None = None, mu_init: float = 0.0, device: int = 0, want_traj: bool = True,
                 want_blob: bool = False, scheme=0, formulation=0, coarse_nodes: int = 0, terminal=0,
-                path: str = "auto") -> BatchResult:
+                path: str = "auto", move_penalty: bool = False) -> BatchResult:
     """Solve a batch of ascent NLPs on one GPU.  params: AscentParams | list | (batch,16) array.
     guess: (21K+10, batch) blob, with warm_start 1 (primal only) or 2 (primal-dual).
     scheme: 0 / "backward_euler" (the reference's NODES=2), 1 / "trapezoid" or 2 / "hermite_simpson" (both with the
@@ -118,6 +118,8 @@ def solve_batch(params, nt: int = 200, tol: float = 1e-9, max_iter: int = 300, g
     terminal: 0 / "reference" (Launch_Optimiser.py:72-78) or 1 / "ellipse" (the (r_peri, r_apo) ellipse proper: vis-viva
     speed at its periapsis; `BatchResult.coast()` then ends at its apoapsis).
     path: "auto" or "dense" (the dense-block path for any scheme).
+    move_penalty: apply the reference's MV DCOST (Launch_Optimiser.py:99): objective tf + dcost * sum |u_k - u_{k-1}| with the
+    `dcost` of each parameter set (dense-block path; default off: `dcost` is then ignored).
     formulation: 0 / "current" or 1 / "v1" (the PDF appendix script: the angle is the MV; see include/ascent.h).
     coarse_nodes: nested iteration for cold starts (0 automatic, -1 single grid, > 0 explicit coarse grid);
     `iters` then counts the iterations of all grid levels."""
@@ -137,7 +139,7 @@ def solve_batch(params, nt: int = 200, tol: float = 1e-9, max_iter: int = 300, g
     tf = np.empty(B)
     status = np.empty(B, dtype=np.int32)
     iters = np.empty(B, dtype=np.int32)
-    o = _opts(nt, max_iter, tol, warm_start, mu_init, scheme, formulation, coarse_nodes, terminal, path)
+    o = _opts(nt, max_iter, tol, warm_start, mu_init, scheme, formulation, coarse_nodes, terminal, path, move_penalty)
     _lib.check(L.ascent_solve_batch(_ptr(P), B, C.byref(o), _ptr(guess), _ptr(traj), _ptr(tf), _ptr(status),
                                     _ptr(iters), _ptr(blob), device, None, 0))
     return BatchResult(P, nt, traj, tf, status, iters, blob, L.ascent_last_kernel_ms(device))
@@ -237,7 +239,7 @@ def kkt_solve(diag, lower, upper, rhs, border=None, border_diag=None, algo="pcr"
 def solve_batch_torch(params_t, nt: int = 200, tol: float = 1e-9, max_iter: int = 300, guess_t=None,
                       warm_start: int = 0, mu_init: float = 0.0, want_traj: bool = True, want_blob: bool = False,
                       out: dict | None = None, sync: bool = False, coarse_nodes: int = 0, scheme=0,
-                      formulation=0) -> dict:
+                      formulation=0, move_penalty: bool = False) -> dict:
     """Device-resident variant: `params_t` is a torch float64 CUDA tensor (batch,16); all outputs are
     torch CUDA tensors (allocated here unless passed in `out`).  Enqueues on torch's current stream
     and returns without waiting unless sync=True.  torch is only the owner of device memory/streams."""
@@ -268,7 +270,7 @@ def solve_batch_torch(params_t, nt: int = 200, tol: float = 1e-9, max_iter: int 
     iters = buf("iters", (B,), torch.int32)
     traj = buf("traj", (10, nt, B), torch.float64) if want_traj else None
     blob = buf("blob", (rows, B), torch.float64) if want_blob else None
-    o = _opts(nt, max_iter, tol, warm_start, mu_init, scheme, formulation, coarse_nodes)
+    o = _opts(nt, max_iter, tol, warm_start, mu_init, scheme, formulation, coarse_nodes, move_penalty=move_penalty)
     stream = torch.cuda.current_stream(dev).cuda_stream
     _lib.check(L.ascent_solve_batch(params_t.data_ptr(), B, C.byref(o),
                                     guess_t.data_ptr() if guess_t is not None else None,
@@ -280,9 +282,9 @@ def solve_batch_torch(params_t, nt: int = 200, tol: float = 1e-9, max_iter: int 
     return out
 
 
-def default_path(batch: int, nt: int = 200, scheme=0, formulation=0) -> str:
+def default_path(batch: int, nt: int = 200, scheme=0, formulation=0, move_penalty: bool = False) -> str:
     """The kernels solve_batch runs for a batch of this size (include/ascent.h: ascent_default_path): a key of _lib.PATHS."""
-    o = _opts(nt, 300, 1e-9, 0, 0.0, scheme, formulation)
+    o = _opts(nt, 300, 1e-9, 0, 0.0, scheme, formulation, move_penalty=move_penalty)
     code = _lib.load().ascent_default_path(int(batch), C.byref(o))
     return {v: k for k, v in _lib.PATHS.items()}[code]
 

@@ -230,6 +230,14 @@ def test_solver_options_of_the_script_are_honoured(golden):
     m.options.NODES = 3
     with pytest.raises(ModelNotRecognised, match="ASCENT_SCHEME"):
         m.solve(disp=False)
+    m.options.NODES = 2
+    m.options.ASCENT_DCOST = 1                                   # the move penalty reaches the solver as move_penalty=True
+    seen.clear()
+    try:
+        m.solve(disp=False)
+    except TypeError:                                            # (the CPU stand-in of these tests has no move penalty)
+        pass
+    assert seen["kw"].get("move_penalty") is True
 
 
 @pytest.mark.gpu
@@ -244,3 +252,29 @@ def test_hermite_simpson_and_ellipse_through_the_front_door():
     m.options.ASCENT_TERMINAL = 1
     m.solve(disp=False)
     assert abs(m.options.OBJFCNVAL * 470.0 - 440.844369) < 1e-4
+
+
+@pytest.mark.gpu
+def test_dcost_through_the_front_door(golden):
+    """m.options.ASCENT_DCOST = 1: the script's own `angledoubledot.DCOST = 1e-5` (Launch_Optimiser.py:99) applied on the HIP
+    path (ascent_opts.move_penalty).  t_f moves by +1.5e-3 s towards Numerical_results.png (20 % of the 7.7e-3 s gap, as the
+    numpy oracle measured), the banner says "applied", no warning."""
+    import json, os, warnings
+    from lunar_module_ascent_trajectory_optimiser_amd.gekko_shim import GEKKO
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "dcost_fixtures.json")))
+    nominal = [c for c in fx["cases"] if c["nt"] == 200 and c["dcost"] == 1e-5][0]
+    ex = _example()
+    m, v, _ = ex.build()
+    m.solve(disp=False)
+    t_off = m.options.OBJFCNVAL
+    GEKKO._dcost_warned = False
+    m.options.ASCENT_DCOST = 1
+    buf = io.StringIO()
+    with redirect_stdout(buf), warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m.solve(disp=True)
+    t_on = m.options.OBJFCNVAL
+    assert "DCOST 1.0e-05: applied" in buf.getvalue() and not any("DCOST" in str(x.message) for x in w)
+    assert abs(t_on - nominal["on"]["tf"]) <= 2e-8 and abs(t_off - nominal["off"]["tf"]) <= 2e-8
+    G = golden["current"]["final_time"]
+    assert 1.0e-3 < (t_on - t_off) * 470.0 < 2.0e-3 and abs(t_on * 470.0 - G) < abs(t_off * 470.0 - G)

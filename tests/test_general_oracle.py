@@ -127,3 +127,20 @@ def test_final_acceleration_gap_is_a_flat_direction_of_the_objective(golden):
     assert 0 <= op["final_time"] - of["final_time"] < 1e-6                             # ... costs nothing to close
     assert abs(op["final_ydoubledot"] / G["final_ydoubledot"] - 1) < 1e-4
     assert abs(op["final_xdoubledot"] / G["final_xdoubledot"] - 1) < 1e-4
+
+
+def test_dcost_fixture_is_what_the_generator_produces():
+    """tests/golden/dcost_fixtures.json (the anchors of ascent_opts.move_penalty on the GPU) against a fresh solve of its smallest
+    case by the numpy generic-LU oracle; every case: the penalty raises t_f by at most dcost * (total variation without it) and
+    lowers the control's total variation."""
+    import json, os
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "dcost_fixtures.json")))
+    c = [c for c in fx["cases"] if c["nt"] == 60 and c["scheme"] == 0 and c["dcost"] == 1e-3][0]
+    nlp = GeneralNLP(Params(), ((59, "burn"),), 0, dcost=1e-3)
+    v, _, info = solve_ip(nlp, tol=1e-10, max_iter=600)
+    assert info["status"] == "converged"
+    assert abs(float(v[nlp.itf]) - c["on"]["tf"]) < 1e-10 and np.abs(v[nlp.ucol] - np.array(c["on"]["u"])).max() < 1e-6
+    assert {(k["nt"], k["scheme"]) for k in fx["cases"]} >= {(60, 0), (60, 1), (41, 2), (200, 0)}
+    for k in fx["cases"]:
+        assert 0.0 < k["on"]["tf"] - k["off"]["tf"] <= k["dcost"] * k["off"]["total_variation"]
+        assert k["on"]["total_variation"] < k["off"]["total_variation"]

@@ -287,3 +287,51 @@ def test_pcr_newton_variant_and_small_batch_dispatch(coracle, monkeypatch):
             coracle.set_scheme(0)
             assert np.abs(res["riccati"].tf - ref["tf"]).max() <= 1e-9 and np.abs(res["riccati"].iters.astype(int) - ref["iters"]).max() <= 1
             assert np.abs(res["auto"].tf - ref["tf"]).max() <= 1e-9 and np.abs(res["auto"].iters.astype(int) - ref["iters"]).max() <= 4
+
+
+def test_move_penalty_matches_independent_fixtures():
+    """a12, Launch_Optimiser.py:99: the MV's DCOST as an l1 term (ascent_opts.move_penalty = 1; dense-block path, the control as the
+    eighth state of a stage, the slack pair reduced to one pivot) against tests/golden/dcost_fixtures.json -- the numpy
+    generic-LU oracle's solutions with and without the penalty (scripts/make_dcost_fixtures.py): backward Euler, trapezoid and
+    Hermite-Simpson, dcost 1e-5 (the reference's) to 1e-3, nominal and off-nominal parameters, nested grids.  t_f to 2e-8
+    (fixtures at tol 1e-10, GPU at 1e-9), the control's total variation to 0.2 %, the control itself to 5e-3 of its [-1, 1]
+    range; switched off, the same call reproduces the unpenalised fixture (dcost is ignored)."""
+    import json, os
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "dcost_fixtures.json")))
+    assert len(fx["cases"]) >= 6
+    for c in fx["cases"]:
+        P = A.AscentParams(**c["params"])
+        for on in (False, True):
+            r = A.solve_batch(P, c["nt"], tol=1e-9, scheme=c["scheme"], max_iter=500, move_penalty=on)
+            ref = c["on" if on else "off"]
+            u = r.traj[8, 1:, 0]
+            tv = np.abs(np.diff(np.concatenate([[0.0], u]))).sum()
+            assert r.status[0] == 0, (c["nt"], c["scheme"], c["dcost"], on)
+            assert abs(r.tf[0] - ref["tf"]) <= 2e-8, (c["nt"], c["scheme"], c["dcost"], on, r.tf[0], ref["tf"])
+            if on:
+                assert abs(tv - ref["total_variation"]) <= 2e-3 * ref["total_variation"]
+                assert np.abs(u - np.array(ref["u"])).max() <= 5e-3
+        assert c["on"]["tf"] > c["off"]["tf"] and c["on"]["total_variation"] < c["off"]["total_variation"]
+    nominal = [c for c in fx["cases"] if c["nt"] == 200 and c["dcost"] == 1e-5][0]
+    assert 1.0e-3 < (nominal["on"]["tf"] - nominal["off"]["tf"]) * 470.0 < 2.0e-3       # +1.5e-3 s on the reference's problem
+
+
+def test_move_penalty_batch_and_dispatch():
+    """A batch through move_penalty = 1: every NLP converges, the penalty raises t_f and lowers the control's total variation on
+    every problem; the default dispatch reports the dense-block path for it; bad values are refused."""
+    S = A.sweep_isp_drymass(3, 3)
+    assert np.all(S[:, 15] == 0.0)                      # (this package's sweeps carry no weight of their own)
+    from lunar_module_ascent_trajectory_optimiser_amd._lib import AscentLibraryError
+    with pytest.raises(AscentLibraryError, match="dcost > 0"):
+        A.solve_batch(S, 100, tol=1e-9, move_penalty=True)
+    S[:, 15] = 1e-5                                     # the reference's DCOST
+    assert A.default_path(9, 100, move_penalty=True) == "dense" and A.default_path(4096, 200, move_penalty=True) == "dense"
+    off = A.solve_batch(S, 100, tol=1e-9)
+    on = A.solve_batch(S, 100, tol=1e-9, move_penalty=True, max_iter=500)
+    assert np.all(off.status == 0) and np.all(on.status == 0)
+    tv = lambda r: np.abs(np.diff(r.traj[8], axis=0)).sum(axis=0)
+    assert np.all(on.tf > off.tf) and np.all(on.tf - off.tf < 1e-4) and np.all(tv(on) < tv(off))
+    # a larger weight flattens the control further
+    S2 = S.copy(); S2[:, 15] = 1e-3
+    on2 = A.solve_batch(S2, 100, tol=1e-9, move_penalty=True, max_iter=500)
+    assert np.all(on2.status == 0) and np.all(tv(on2) < tv(on)) and np.all(on2.tf > on.tf)

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol(lib):
 
 def test_struct_layouts_match_header():
     assert C.sizeof(_lib.AscentParamsC) == 16 * 8
-    assert C.sizeof(_lib.AscentOptsC) == 48
+    assert C.sizeof(_lib.AscentOptsC) == 56 and [f[0] for f in _lib.AscentOptsC._fields_][-2:] == ["move_penalty", "reserved"]
     assert tuple(n for n, _ in _lib.AscentParamsC._fields_) == A.PARAM_FIELDS
 
 
