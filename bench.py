@@ -125,7 +125,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch-per-gpu", type=int, default=4096)
     ap.add_argument("--tol", type=float, default=1e-9)
-    ap.add_argument("--cpu-sample", type=int, default=2048)
+    ap.add_argument("--cpu-sample", type=int, default=4096)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-continuation", action="store_true", help="skip the secondary warm-start (continuation) measurement")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the secondary two-stream (overlapped batches) measurement")
