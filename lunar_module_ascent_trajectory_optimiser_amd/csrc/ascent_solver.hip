@@ -1286,6 +1286,7 @@ int ascent_eval_nodes_path(const ascent_params *p, int64_t batch, const ascent_o
                            double *defects, double *jac_blocks, double *hess_blocks, int device_id, int path) {
   int rc = check_common(p, batch, o, device_id);
   if (rc) return rc;
+  if (o->move_penalty) { snprintf(g_err, sizeof g_err, "the parity surfaces take the unpenalised NLP only (move_penalty = 1 is an option of ascent_solve_batch)"); return ASCENT_E_ARG; }
   if (!iterate || !defects || !jac_blocks || !hess_blocks) { snprintf(g_err, sizeof g_err, "null pointer"); return ASCENT_E_ARG; }
   if (path < ASCENT_PATH_AUTO || path > ASCENT_PATH_DENSE) { snprintf(g_err, sizeof g_err, "unknown path %d", path); return ASCENT_E_ARG; }
   path = resolve_path(path, o, batch);
@@ -1331,6 +1332,7 @@ int ascent_kkt_step_path(const ascent_params *p, int64_t batch, const ascent_opt
                          int path) {
   int rc = check_common(p, batch, o, device_id);
   if (rc) return rc;
+  if (o->move_penalty) { snprintf(g_err, sizeof g_err, "the parity surfaces take the unpenalised NLP only (move_penalty = 1 is an option of ascent_solve_batch)"); return ASCENT_E_ARG; }
   if (!iterate || !mu || !delta_w || !step || !inertia_out) { snprintf(g_err, sizeof g_err, "null pointer"); return ASCENT_E_ARG; }
   if (path < ASCENT_PATH_AUTO || path > ASCENT_PATH_PERSIST) { snprintf(g_err, sizeof g_err, "unknown path %d", path); return ASCENT_E_ARG; }
   path = resolve_path(path, o, batch, true);
@@ -1387,6 +1389,7 @@ int ascent_dense_records(const ascent_params *p, int64_t batch, const ascent_opt
                          double *records, int device_id) {
   int rc = check_common(p, batch, o, device_id);
   if (rc) return rc;
+  if (o->move_penalty) { snprintf(g_err, sizeof g_err, "the parity surfaces take the unpenalised NLP only (move_penalty = 1 is an option of ascent_solve_batch)"); return ASCENT_E_ARG; }
   if (!iterate || !records) { snprintf(g_err, sizeof g_err, "null pointer"); return ASCENT_E_ARG; }
   if (o->formulation != 0) { snprintf(g_err, sizeof g_err, "the dense-block path has formulation 0 only"); return ASCENT_E_ARG; }
   std::lock_guard<std::mutex> lock(g_mu[device_id]);

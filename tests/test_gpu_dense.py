@@ -335,3 +335,23 @@ def test_move_penalty_batch_and_dispatch():
     S2 = S.copy(); S2[:, 15] = 1e-3
     on2 = A.solve_batch(S2, 100, tol=1e-9, move_penalty=True, max_iter=500)
     assert np.all(on2.status == 0) and np.all(tv(on2) < tv(on)) and np.all(on2.tf > on.tf)
+
+
+def test_move_penalty_across_the_config4_box_and_on_long_grids():
+    """move_penalty = 1 away from the nominal problem and on long grids: 64 problems across BASELINE config 4's box (the
+    reference's weight 1e-5) all converge, t_f rises by 1e-3 .. 2e-3 s on each; N = 1000 trapezoid and N = 2000 Hermite-Simpson
+    with the ellipse terminal condition (config 5's grid) converge, t_f + 1.6e-3 s, the control's total variation 7.3 -> 4.4."""
+    S = A.sweep_config4()[::4099][:64].copy()
+    S[:, 15] = 1e-5
+    off = A.solve_batch(S, 200, tol=1e-9, want_traj=False)
+    on = A.solve_batch(S, 200, tol=1e-9, want_traj=False, move_penalty=True, max_iter=500)
+    assert np.all(off.status == 0) and np.all(on.status == 0)
+    shift = (on.tf - off.tf) * 470.0
+    assert shift.min() > 5e-4 and shift.max() < 3e-3
+    P = A.AscentParams(dcost=1e-5)
+    tv = lambda r: np.abs(np.diff(np.concatenate([[0.0], r.traj[8, 1:, 0]]))).sum()
+    for nt, scheme, term in ((1000, 1, "reference"), (2000, 2, "ellipse")):
+        r0 = A.solve_batch(P, nt, tol=1e-9, scheme=scheme, terminal=term, max_iter=500)
+        r1 = A.solve_batch(P, nt, tol=1e-9, scheme=scheme, terminal=term, max_iter=500, move_penalty=True)
+        assert r0.status[0] == 0 and r1.status[0] == 0
+        assert 1.0e-3 < (r1.tf[0] - r0.tf[0]) * 470.0 < 2.5e-3 and tv(r1) < 0.7 * tv(r0)
