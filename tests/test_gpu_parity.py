@@ -541,6 +541,11 @@ torch.cuda.synchronize(dev)
 for o, r in ((oa, ref_a), (ob, ref_b)):
     assert bool((o["status"] == 0).all()) and torch.equal(o["iters"], r["iters"])
     assert torch.equal(o["tf"], r["tf"]) and torch.equal(o["traj"], r["traj"])
+# the move penalty through the device-resident entry (parameters in HBM: the positive-weight check is the caller's)
+Pc = Pa[:8].clone(); Pc[:, 15] = 1e-5
+mp = A.solve_batch_torch(Pc, 100, tol=1e-9, sync=True, move_penalty=True, max_iter=500)
+host = A.solve_batch(Pc.cpu().numpy(), 100, tol=1e-9, move_penalty=True, max_iter=500)
+assert bool((mp["status"] == 0).all()) and np.array_equal(mp["tf"].cpu().numpy(), host.tf) and np.all(host.tf > ref_a["tf"][:8].cpu().numpy() - 1.0)
 print("two-streams-ok")
 """
 
