@@ -80,6 +80,12 @@ def test_argument_validation(lib):
         o3 = _lib.AscentOptsC(n_nodes=200, scheme=0, max_iter=10, warm_start=0, tol=1e-8, mu_init=0.0, coarse_nodes=bad)
         rc = lib.ascent_solve_batch(P.ctypes.data_as(C.c_void_p), 1, C.byref(o3), None, None, None, None, None, None, 0, None, 0)
         assert rc == -1 and b"coarse_nodes" in lib.ascent_strerror(rc)
+    o4 = _lib.AscentOptsC(n_nodes=200, scheme=0, max_iter=10, warm_start=0, tol=1e-8, mu_init=0.0, move_penalty=2)
+    rc = lib.ascent_solve_batch(P.ctypes.data_as(C.c_void_p), 1, C.byref(o4), None, None, None, None, None, None, 0, None, 0)
+    assert rc == -1 and b"move_penalty" in lib.ascent_strerror(rc)
+    o5 = _lib.AscentOptsC(n_nodes=200, scheme=0, max_iter=10, warm_start=0, tol=1e-8, mu_init=0.0, move_penalty=1, formulation=1)
+    rc = lib.ascent_solve_batch(P.ctypes.data_as(C.c_void_p), 1, C.byref(o5), None, None, None, None, None, None, 0, None, 0)
+    assert rc == -1 and b"formulation 0" in lib.ascent_strerror(rc)
 
 
 def test_product_does_not_import_oracle():
@@ -95,7 +101,8 @@ def test_product_does_not_import_oracle():
 def test_default_path_dispatch_rule(monkeypatch):
     """ascent_default_path (include/ascent.h): which kernels a solve of that size runs -- no device work, so checked here.
     Schemes 0 and 1 and the v1 formulation: the persistent kernel, except (formulation 0) a handful of NLPs on a long grid
-    (>= 400 intervals, batch <= min(8, intervals/75)), which take the dense blocks + PCR; scheme 2: dense blocks always."""
+    (>= 400 intervals, batch <= min(8, intervals/75)), which take the dense blocks + PCR; scheme 2 and the move penalty
+    (ascent_opts.move_penalty, the reference's DCOST): dense blocks always."""
     import lunar_module_ascent_trajectory_optimiser_amd as A
     for k in ("ASCENT_PIPELINE", "ASCENT_FACTOR", "ASCENT_SMALL_BATCH", "ASCENT_DENSE_NEWTON"):
         monkeypatch.delenv(k, raising=False)
@@ -106,6 +113,7 @@ def test_default_path_dispatch_rule(monkeypatch):
     assert [A.default_path(b, 2000, scheme=1) for b in (8, 9)] == ["dense", "persist"]
     assert [A.default_path(b, 201, formulation=1) for b in (1, 4096, 8192)] == ["persist"] * 3 and A.default_path(4, 2000, formulation=1) == "persist"
     assert A.default_path(4096, 201, scheme=2) == "dense"
+    assert [A.default_path(b, 201, scheme=sc, move_penalty=True) for b in (1, 4096) for sc in (0, 1, 2)] == ["dense"] * 6     # the l1 move penalty
     assert A.default_path(1, 2000) == "dense"
     monkeypatch.setenv("ASCENT_SMALL_BATCH", "off")
     assert A.default_path(1, 2000) == "persist"
