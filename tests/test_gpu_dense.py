@@ -335,6 +335,15 @@ def test_move_penalty_batch_and_dispatch():
     S2 = S.copy(); S2[:, 15] = 1e-3
     on2 = A.solve_batch(S2, 100, tol=1e-9, move_penalty=True, max_iter=500)
     assert np.all(on2.status == 0) and np.all(tv(on2) < tv(on)) and np.all(on2.tf > on.tf)
+    # nine orders of magnitude of the weight in one batch: all converge, t_f and the total variation are monotone in it,
+    # and the rise of t_f is bounded by the penalty the unpenalised control would pay
+    W = np.array([1e-9, 1e-7, 1e-5, 1e-3, 1e-1, 1.0])
+    Sw = np.tile(A.AscentParams().as_row(), (len(W), 1)); Sw[:, 15] = W
+    rw = A.solve_batch(Sw, 200, tol=1e-9, move_penalty=True, max_iter=500)
+    r0 = A.solve_batch(Sw[:1], 200, tol=1e-9)
+    assert np.all(rw.status == 0) and rw.iters.max() <= 60
+    assert np.all(np.diff(rw.tf) > 0) and np.all(np.diff(tv(rw)) < 0)
+    assert np.all(rw.tf - r0.tf[0] <= W * tv(r0)[0] + 1e-9) and rw.tf[0] - r0.tf[0] < 1e-8
 
 
 def test_move_penalty_across_the_config4_box_and_on_long_grids():
