@@ -550,8 +550,12 @@ struct Border { double Oth, Otn, Onn, oth, onu; };     // Omega (2x2 symmetric) 
 #ifdef DENSE_TRACE
 ASC_DEV double s0th_dbg(const double *sc) { return sc[X_S + S_TH]; }
 #endif
-template <int MODE>
-__global__ __launch_bounds__(WAVE) void d_newton(const ascent_params *params, long batch, DGeo g, double *ws, int max_iter,
+// PIPE = 1: the inputs of a recursion step are loaded one step ahead (they do not depend on the recursion; a step is
+// otherwise a chain of dependent HBM round trips in front of every product).  That needs 291 registers = one wavefront per
+// SIMD, which pays while the batch does not offer more than one anyway (<= 1024 NLPs: -18 %; 4096 NLPs: +11 %, so the host
+// picks PIPE = 0 there: same code, loads at the top of the step, two wavefronts per SIMD).
+template <int MODE, int PIPE = 0>
+__global__ __launch_bounds__(WAVE, PIPE ? 1 : 2) void d_newton(const ascent_params *params, long batch, DGeo g, double *ws, int max_iter,
                                                  double tol, int probe, const double *probe_dw, int *counters) {
   __shared__ Lds8 L;
   const long p = blockIdx.x;
@@ -686,20 +690,39 @@ __global__ __launch_bounds__(WAVE) void d_newton(const ascent_params *params, lo
     double R = 0.0;                      // grid of vectors: column 0 = p, column 1 = Pi_theta, column 2 = Pi_nu3
     Border B{0.0, 0.0, 0.0, 0.0, tm.e3};
     int bad = 0;
-    for (int k = K - 1; k >= 0; k--) {
+    // One step's inputs are loaded while the step before is computed: they do not depend on the recursion, and a step is
+    // otherwise a chain of dependent HBM round trips (records, node quantities) in front of every product.
+    struct StepIn { double Ja, Jb, Haa, Hab, Hbb, V, a_, m_, u_, zb[6], gb, ga, lw, Huth, Hthth, pp, pn, zp, zn, lu; };
+    auto load_step = [&](int k, StepIn &q) __attribute__((always_inline)) {
       const double *rec = rec0 + (size_t)k * NGRID * 64;
-      const double Ja = rec[G_JA * 64 + l], Jb = rec[G_JB * 64 + l], Haa = rec[G_HAA * 64 + l], Hab = rec[G_HAB * 64 + l];
-      double Fxx = rec[G_HBB * 64 + l] + P;
-      const double V = rec[G_V * 64 + l];
-      // node quantities of this step (uniform loads)
-      const double a_ = it[(O_Z + IA) * K + k], m_ = it[(O_Z + IM) * K + k], u_ = it[O_U * K + k];
+      q.Ja = rec[G_JA * 64 + l]; q.Jb = rec[G_JB * 64 + l]; q.Haa = rec[G_HAA * 64 + l]; q.Hab = rec[G_HAB * 64 + l];
+      q.Hbb = rec[G_HBB * 64 + l]; q.V = rec[G_V * 64 + l];
+      q.a_ = it[(O_Z + IA) * K + k]; q.m_ = it[(O_Z + IM) * K + k]; q.u_ = it[O_U * K + k];
+      ASC_UNROLL
+      for (int b = 0; b < 6; b++) q.zb[b] = it[(O_ZB + b) * K + k];
+      q.gb = nv[(NV_GB + i) * K + k]; q.ga = k + 1 < K ? nv[(NV_GA + i) * K + k + 1] : 0.0;
+      q.lw = it[(O_L + IW) * K + k];
+      q.Huth = nv[(NV_P + 8) * K + k]; q.Hthth = nv[(NV_P + 9) * K + k];
+      if (g.dc) { q.pp = it[O_PP * K + k]; q.pn = it[O_PN * K + k]; q.zp = it[O_ZP * K + k]; q.zn = it[O_ZN * K + k]; q.lu = it[O_LU * K + k]; }
+      else { q.pp = q.pn = 1.0; q.zp = q.zn = q.lu = 0.0; }
+    };
+    StepIn cur_, nxt_;
+    if (PIPE) { load_step(K - 1, cur_); nxt_ = cur_; }
+    for (int k = K - 1; k >= 0; k--) {
+      if (!PIPE) load_step(k, cur_);
+      else if (k > 0) load_step(k - 1, nxt_);
+      const double Ja = cur_.Ja, Jb = cur_.Jb, Haa = cur_.Haa, Hab = cur_.Hab;
+      double Fxx = cur_.Hbb + P;
+      const double V = cur_.V;
+      // node quantities of this step
+      const double a_ = cur_.a_, m_ = cur_.m_, u_ = cur_.u_;
       const double id0 = rcp(a_), id1 = rcp(d.aub - a_), id2 = rcp(m_), id3 = rcp(1.0 - m_), id4 = rcp(u_ + 1.0), id5 = rcp(1.0 - u_);
-      const double siga = it[(O_ZB + 0) * K + k] * id0 + it[(O_ZB + 1) * K + k] * id1;
-      const double sigm = it[(O_ZB + 2) * K + k] * id2 + it[(O_ZB + 3) * K + k] * id3;
-      double sigu = it[(O_ZB + 4) * K + k] * id4 + it[(O_ZB + 5) * K + k] * id5;
+      const double siga = cur_.zb[0] * id0 + cur_.zb[1] * id1;
+      const double sigm = cur_.zb[2] * id2 + cur_.zb[3] * id3;
+      double sigu = cur_.zb[4] * id4 + cur_.zb[5] * id5;
       if (i == j) Fxx += (i == IA ? siga : i == IM ? sigm : (i == 7 && g.dc) ? sigu : 0.0) + dw;
       // residual of node k (barrier form), row-indexed: r_i in lane (i, *)
-      double rx = (i < 7 || g.dc) ? nv[(NV_GB + i) * K + k] + (k + 1 < K ? nv[(NV_GA + i) * K + k + 1] : 0.0) : 0.0;
+      double rx = (i < 7 || g.dc) ? cur_.gb + cur_.ga : 0.0;
       if (i == IA) rx += mu * (id1 - id0);
       if (i == IM) rx += mu * (id3 - id2);
       if (i == 7 && g.dc) rx += mu * (id5 - id4);
@@ -724,15 +747,15 @@ __global__ __launch_bounds__(WAVE) void d_newton(const ascent_params *params, lo
         rx += rt;
         Fxb_nu += e3;
       }
-      double ru = -dt * d.alpha * it[(O_L + IW) * K + k] + mu * (id5 - id4);     // Ju'lambda + barrier gradient
+      double ru = -dt * d.alpha * cur_.lw + mu * (id5 - id4);     // Ju'lambda + barrier gradient
       if (g.dc) {      // the stage's control is delta = p - n: curvature and gradient of the reduced slack pair
-        const double pp = it[O_PP * K + k], pn = it[O_PN * K + k], lu = it[O_LU * K + k];
+        const double pp = cur_.pp, pn = cur_.pn, lu = cur_.lu;
         const double ip = rcp(pp), in_ = rcp(pn);
-        const double isp = rcp(it[O_ZP * K + k] * ip + dw), isn = rcp(it[O_ZN * K + k] * in_ + dw);
+        const double isp = rcp(cur_.zp * ip + dw), isn = rcp(cur_.zn * in_ + dw);
         sigu = rcp(isp + isn);
         ru = sigu * ((dcw - mu * ip - lu) * isp - (dcw - mu * in_ + lu) * isn);
       }
-      const double Huth = nv[(NV_P + 8) * K + k], Hthth = nv[(NV_P + 9) * K + k];
+      const double Huth = cur_.Huth, Hthth = cur_.Hthth;
       // vectors of the record, row-indexed (component i in lane (i,*))
       const double cvec = rowvec_t(V, 0), Ju = rowvec_t(V, 1), Jth = rowvec_t(V, 2), Hath = rowvec_t(V, 3), Hbth = rowvec_t(V, 4);
       const double fx = rx + colvec(R, 0);                       // f_x = r^x + p
@@ -780,6 +803,7 @@ __global__ __launch_bounds__(WAVE) void d_newton(const ascent_params *params, lo
       fw[F_EL2 * 64 + l] = j < 4 ? E2 : L2s;                     // [Eu Eth 0 e | Lu Lth Lnu Le]
       if (i == 0) fw[F_GAIN * 64 + j] = Gxu_c * iD;
       if (l == 8) { fw[F_GAIN * 64 + 8] = ku_th; fw[F_GAIN * 64 + 9] = ku_nu; fw[F_GAIN * 64 + 10] = ku_0; }
+      if (PIPE) cur_ = nxt_;
     }
     bad = __any(bad);
     int ok = !bad;
@@ -814,11 +838,29 @@ __global__ __launch_bounds__(WAVE) void d_newton(const ascent_params *params, lo
   double *st = w + g.off_st();
   double xi = 0.0;                     // dz_{k-1}, column-indexed (component j in lane (*, j))
   double rmax = 0.0, gsum = 0.0, adu = 1.0, cl = 0.0, dzK = 0.0, gmove = 0.0;
-  for (int k = 0; k < K; k++) {
+  // (the inputs of a step are loaded while the step before is computed, as in the backward recursion)
+  struct FwdIn { double Ea, La, EL2, kg, ku_th, ku_nu, ku_0, a_, m_, u_, zb[6], V, lam_i, pp, pn, zp, zn, lu; };
+  auto load_fwd = [&](int k, FwdIn &q) __attribute__((always_inline)) {
     const double *fw = fwd0 + (size_t)k * FWD_DOUBLES;
-    const double Ea = fw[F_EA * 64 + l], La = fw[F_LA * 64 + l], EL2 = fw[F_EL2 * 64 + l];
-    const double kg = fw[F_GAIN * 64 + j];
-    const double ku_th = fw[F_GAIN * 64 + 8], ku_nu = fw[F_GAIN * 64 + 9], ku_0 = fw[F_GAIN * 64 + 10];
+    q.Ea = fw[F_EA * 64 + l]; q.La = fw[F_LA * 64 + l]; q.EL2 = fw[F_EL2 * 64 + l];
+    q.kg = fw[F_GAIN * 64 + j];
+    q.ku_th = fw[F_GAIN * 64 + 8]; q.ku_nu = fw[F_GAIN * 64 + 9]; q.ku_0 = fw[F_GAIN * 64 + 10];
+    q.a_ = it[(O_Z + IA) * K + k]; q.m_ = it[(O_Z + IM) * K + k]; q.u_ = it[O_U * K + k];
+    ASC_UNROLL
+    for (int b = 0; b < 6; b++) q.zb[b] = it[(O_ZB + b) * K + k];
+    q.V = (w + g.off_rec() + (size_t)k * NGRID * 64)[G_V * 64 + l];
+    q.lam_i = i < 7 ? it[(O_L + i) * K + k] : g.dc ? it[O_LU * K + k] : 0.0;
+    if (g.dc) { q.pp = it[O_PP * K + k]; q.pn = it[O_PN * K + k]; q.zp = it[O_ZP * K + k]; q.zn = it[O_ZN * K + k]; q.lu = it[O_LU * K + k]; }
+    else { q.pp = q.pn = 1.0; q.zp = q.zn = q.lu = 0.0; }
+  };
+  FwdIn fc_, fn_;
+  if (PIPE) { load_fwd(0, fc_); fn_ = fc_; }
+  for (int k = 0; k < K; k++) {
+    if (!PIPE) load_fwd(k, fc_);
+    else if (k + 1 < K) load_fwd(k + 1, fn_);
+    const double Ea = fc_.Ea, La = fc_.La, EL2 = fc_.EL2;
+    const double kg = fc_.kg;
+    const double ku_th = fc_.ku_th, ku_nu = fc_.ku_nu, ku_0 = fc_.ku_0;
     const double du = -(rowsum(kg * xi) + ku_th * dth + ku_nu * dnu3 + ku_0);
     const double yv = j == 0 ? du : j == 1 ? dth : j == 2 ? dnu3 : j == 3 ? 1.0 : 0.0;       // (u, theta, nu, 1)
     const double yl = j == 4 ? du : j == 5 ? dth : j == 6 ? dnu3 : j == 7 ? 1.0 : 0.0;
@@ -829,7 +871,7 @@ __global__ __launch_bounds__(WAVE) void d_newton(const ascent_params *params, lo
     if (g.dc) {
       const double dlu = pick(dl, 7, 0);
       du_ = pick(dz, 7, 0);
-      const double pp = it[O_PP * K + k], pn = it[O_PN * K + k], zp = it[O_ZP * K + k], zn = it[O_ZN * K + k], lu = it[O_LU * K + k];
+      const double pp = fc_.pp, pn = fc_.pn, zp = fc_.zp, zn = fc_.zn, lu = fc_.lu;
       const double ip = rcp(pp), in_ = rcp(pn);
       // the slack with the larger curvature from its own row (well conditioned), the other from delta = p - n (its own row
       // divides a difference of two nearly equal numbers by a curvature that vanishes for an inactive slack)
@@ -851,7 +893,7 @@ __global__ __launch_bounds__(WAVE) void d_newton(const ascent_params *params, lo
     if (l == 0) st[O_U * K + k] = du_;
     // bound multipliers and both fraction-to-boundary rules (every lane redundantly)
     const double dza = pick(dz, IA, 0), dzm = pick(dz, IM, 0);
-    const double a_ = it[(O_Z + IA) * K + k], m_ = it[(O_Z + IM) * K + k], u_ = it[O_U * K + k];
+    const double a_ = fc_.a_, m_ = fc_.m_, u_ = fc_.u_;
     const double id[6] = {rcp(a_), rcp(d.aub - a_), rcp(m_), rcp(1.0 - m_), rcp(u_ + 1.0), rcp(1.0 - u_)};
     ASC_FTBR(rmax, id[0], dza); ASC_FTBR(rmax, id[1], -dza);
     ASC_FTBR(rmax, id[2], dzm); ASC_FTBR(rmax, id[3], -dzm);
@@ -860,19 +902,20 @@ __global__ __launch_bounds__(WAVE) void d_newton(const ascent_params *params, lo
     const double dx3[3] = {dza, dzm, du_};
     ASC_UNROLL
     for (int b = 0; b < 3; b++) {
-      const double zl = it[(O_ZB + 2 * b) * K + k], zu = it[(O_ZB + 2 * b + 1) * K + k];
+      const double zl = fc_.zb[2 * b], zu = fc_.zb[2 * b + 1];
       const double dzl = id[2 * b] * (mu - zl * dx3[b]) - zl, dzu = id[2 * b + 1] * (mu + zu * dx3[b]) - zu;
       ASC_FTB(adu, zl, dzl);
       ASC_FTB(adu, zu, dzu);
       if (l == 0) { st[(O_ZB + 2 * b) * K + k] = dzl; st[(O_ZB + 2 * b + 1) * K + k] = dzu; }
     }
     // c'(lambda + dlambda) for the curvature estimate of the merit function
-    const double V = (w + g.off_rec() + (size_t)k * NGRID * 64)[G_V * 64 + l];
+    const double V = fc_.V;
     const double cvec = rowvec_t(V, 0);
-    const double lam_i = i < 7 ? it[(O_L + i) * K + k] : g.dc ? it[O_LU * K + k] : 0.0;
+    const double lam_i = fc_.lam_i;
     cl += j == 0 ? cvec * (lam_i + dl) : 0.0;
     xi = __shfl(dz, j << 3);           // next step's xi_j = dz_j
     if (k == K - 1) dzK = dz;
+    if (PIPE) fc_ = fn_;
   }
   cl = wsum(cl);
   // ---- scalars of the step, merit bookkeeping ---------------------------------------------------------------------------
@@ -1339,8 +1382,12 @@ int dense_run(const ascent_params *dp, long batch, int K, int scheme, int termin
       DCHK(hipMemsetAsync(counters, 0, sizeof(int), stream));
       hipLaunchKernelGGL(d_eval, ngrid, dim3(WAVE), 0, stream, dp, batch, g, ws);
       if (!pcr) {
-        hipLaunchKernelGGL(d_newton<0>, dim3((unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g, ws, max_iter, tol, 0,
-                           (const double *)nullptr, counters);
+        if (batch <= 1024)       // (at most one wavefront per SIMD: the pipelined variant)
+          hipLaunchKernelGGL((d_newton<0, 1>), dim3((unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g, ws, max_iter, tol, 0,
+                             (const double *)nullptr, counters);
+        else
+          hipLaunchKernelGGL((d_newton<0, 0>), dim3((unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g, ws, max_iter, tol, 0,
+                             (const double *)nullptr, counters);
       } else {
         hipLaunchKernelGGL(d_newton<1>, dim3((unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g, ws, max_iter, tol, 0,
                            (const double *)nullptr, counters);
