@@ -686,6 +686,24 @@ __global__ __launch_bounds__(WAVE, PIPE ? 1 : 2) void d_newton(const ascent_para
   for (;;) {
     sig1 = s.zs1 * is1 + dw; sig2 = s.zs2 * is2 + dw;
     rs1 = -mu * is1 - s.nu1; rs2 = -mu * is2 - s.nu2;
+    // the terminal terms of the last node, per lane: its element of the terminal Hessian, its rows of the terminal gradients
+    double term_add = 0.0, term_rt = 0.0, term_e3 = 0.0;
+    {
+      const double w1 = s.nu1 + sig1 * cg1 + rs1, w2 = s.nu2 + sig2 * cg2 + rs2;
+      double QT[28];
+      ASC_UNROLL
+      for (int q = 0; q < 28; q++) QT[q] = 0.0;
+      terminal_hessian(QT, tm, s.nu3, s.nu1, s.nu2, sig1, sig2);
+      ASC_UNROLL
+      for (int a = 0; a < 4; a++) {
+        ASC_UNROLL
+        for (int b = 0; b < 4; b++) term_add = (i == a && j == b) ? QT[sid(a, b)] : term_add;
+      }
+      const double rt4[4] = {s.nu3 * tm.e3g[0] + w1 * tm.g1g[0], s.nu3 * tm.e3g[1] + w1 * tm.g1g[1],
+                             s.nu3 * tm.e3g[2] + w2 * tm.g2g[0], s.nu3 * tm.e3g[3] + w2 * tm.g2g[1]};
+      ASC_UNROLL
+      for (int a = 0; a < 4; a++) { term_rt = i == a ? rt4[a] : term_rt; term_e3 = i == a ? tm.e3g[a] : term_e3; }
+    }
     double P = 0.0;                      // value-function Hessian (grid)
     double R = 0.0;                      // grid of vectors: column 0 = p, column 1 = Pi_theta, column 2 = Pi_nu3
     Border B{0.0, 0.0, 0.0, 0.0, tm.e3};
@@ -727,26 +745,7 @@ __global__ __launch_bounds__(WAVE, PIPE ? 1 : 2) void d_newton(const ascent_para
       if (i == IM) rx += mu * (id3 - id2);
       if (i == 7 && g.dc) rx += mu * (id5 - id4);
       double Fxb_nu = colvec(R, 2);        // F_x,nu3 = Pi_nu3 (+ terminal gradient of r.v), row-indexed
-      if (k == K - 1) {
-        const double w1 = s.nu1 + sig1 * cg1 + rs1, w2 = s.nu2 + sig2 * cg2 + rs2;
-        double QT[28];
-        ASC_UNROLL
-        for (int q = 0; q < 28; q++) QT[q] = 0.0;
-        terminal_hessian(QT, tm, s.nu3, s.nu1, s.nu2, sig1, sig2);
-        double add = 0.0, rt = 0.0, e3 = 0.0;
-        ASC_UNROLL
-        for (int a = 0; a < 4; a++) {
-          ASC_UNROLL
-          for (int b = 0; b < 4; b++) add = (i == a && j == b) ? QT[sid(a, b)] : add;
-        }
-        Fxx += add;
-        const double rt4[4] = {s.nu3 * tm.e3g[0] + w1 * tm.g1g[0], s.nu3 * tm.e3g[1] + w1 * tm.g1g[1],
-                               s.nu3 * tm.e3g[2] + w2 * tm.g2g[0], s.nu3 * tm.e3g[3] + w2 * tm.g2g[1]};
-        ASC_UNROLL
-        for (int a = 0; a < 4; a++) { rt = i == a ? rt4[a] : rt; e3 = i == a ? tm.e3g[a] : e3; }
-        rx += rt;
-        Fxb_nu += e3;
-      }
+      if (k == K - 1) { Fxx += term_add; rx += term_rt; Fxb_nu += term_e3; }      // the last node's terminal terms (formed above)
       double ru = -dt * d.alpha * cur_.lw + mu * (id5 - id4);     // Ju'lambda + barrier gradient
       if (g.dc) {      // the stage's control is delta = p - n: curvature and gradient of the reduced slack pair
         const double pp = cur_.pp, pn = cur_.pn, lu = cur_.lu;
