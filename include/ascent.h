@@ -81,7 +81,7 @@ typedef struct ascent_opts {
                            1 = :99 angledoubledot.DCOST applied: the objective is tf + dcost * sum_k |u_k - u_{k-1}|
                                (u_{-1} = 0, the MV's initial value; an l1 term with a slack pair per step, as APMonitor
                                documents DCOST).  Any scheme, formulation 0; carried by the dense-block path (the control
-                               becomes the eighth state of a stage), Riccati form                                   */
+                               becomes the eighth state of a stage)                                                 */
   int32_t reserved;     /* 0 */
 } ascent_opts;
 

@@ -63,7 +63,7 @@ enum {  // scalar record
   X_S,                       // 10 scalars of the iterate: th zlt zut s1 s2 zs1 zs2 nu3 nu1 nu2
   X_D = X_S + 10,            // 10 scalars of the step
   X_T = X_D + 10,            // 10 trial scalars
-  X_REFAC = X_T + 10, X_RTH, X_DW,
+  X_REFAC = X_T + 10, X_RTH, X_DW, X_MV,
   NSCAL = 64
 };
 enum { ST_TRIAL = 0, ST_NEWTON = 1, ST_DONE = 3 };     // ST_NEWTON: waiting for the PCR solve of its Newton system
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(WAVE, PIPE ? 1 : 2) void d_newton(const ascent_para
   }
   if (MODE == 1) {
     if (l == 0) {
-      sc[X_MU] = mu; sc[X_NUP] = nu_pen; sc[X_RTH] = rth; sc[X_DW] = dw; sc[X_STATE] = ST_NEWTON;
+      sc[X_MU] = mu; sc[X_NUP] = nu_pen; sc[X_RTH] = rth; sc[X_DW] = dw; sc[X_MV] = mv; sc[X_STATE] = ST_NEWTON;
       atomicAdd(&counters[0], 1);
     }
     return;
@@ -966,7 +966,11 @@ __global__ __launch_bounds__(WAVE, PIPE ? 1 : 2) void d_newton(const ascent_para
 // would be the Lagrangian Hessian, which is tiny and indefinite).  PCR exposes no inertia; this variant regularises on
 // the curvature dx'(W + Sigma + delta)dx along the step, which the merit function needs anyway.
 // ==============================================================================================================
-constexpr int PC_NB = 2, PC_BS = 15;
+// With the move penalty (DC = 1) the control is the eighth state and the stage's control delta = p - n is eliminated into the
+// movement equation (d delta = (d lambda_u - g)/R: a diagonal entry -1/R): 16x16 blocks, rows (8 constraint rows, 8
+// stationarity rows) against unknowns (8 states, 8 multipliers).
+constexpr int PC_NB = 2, PC_BS = 15, PC_BSMAX = 16;
+template <int DC>
 __global__ __launch_bounds__(WAVE) void pc_assemble(const ascent_params *params, long batch, DGeo g, const double *ws, double *bt,
                                                     double *bcols, size_t node_doubles) {
   const long p = blockIdx.y;
@@ -1005,10 +1009,59 @@ __global__ __launch_bounds__(WAVE) void pc_assemble(const ascent_params *params,
   }
   double *o = bt + ((size_t)p * K + k) * node_doubles;
   const int c = l & 15;
+  double iR = 0.0, gR = 0.0;                                  // (DC) 1/R and g/R of the reduced slack pair
+  if (DC) {
+    const double pp = it[O_PP * K + k], pn = it[O_PN * K + k], lu = it[O_LU * K + k], dcw = params[p].dcost;
+    const double ip = rcp(pp), in_ = rcp(pn);
+    const double isp = rcp(it[O_ZP * K + k] * ip + dw), isn = rcp(it[O_ZN * K + k] * in_ + dw);
+    iR = isp + isn;
+    gR = (dcw - mu * ip - lu) * isp - (dcw - mu * in_ + lu) * isn;
+  }
   ASC_UNROLL
   for (int q = 0; q < 4; q++) {
     const int rp = (l >> 4) + 4 * q;                          // physical row: 0-6 defect rows, 7 control row, 8-14 state rows
     double L = 0.0, D = 0.0, U = 0.0, R = 0.0;
+    if (DC) {
+      if (rp < 8) {                                           // constraint row i (7: the movement equation, delta eliminated)
+        const int i = rp;
+        if (c < 8) { D = rk[G_JB * 64 + i * 8 + c]; if (k > 0) L = rk[G_JA * 64 + i * 8 + c]; }
+        else if (i == 7 && c == 15) D = -iR;
+        if (c == 0) R = -rk[G_V * 64 + 0 * 8 + i] - (i == 7 ? gR : 0.0);
+        else if (c == 1) R = rk[G_V * 64 + 2 * 8 + i];
+      } else {                                                // stationarity with respect to state i (7: the control)
+        const int i = rp - 8;
+        if (c < 8) {
+          D = rk[G_HBB * 64 + i * 8 + c] + (nxt ? rn[G_HAA * 64 + i * 8 + c] : 0.0);
+          if (i == c) D += (i == IA ? siga : i == IM ? sigm : i == 7 ? sigu : 0.0) + dw;
+          if (last) {
+            ASC_UNROLL
+            for (int a = 0; a < 4; a++) {
+              ASC_UNROLL
+              for (int b = 0; b < 4; b++) D += (i == a && c == b) ? QT[sid(a, b)] : 0.0;
+            }
+          }
+          if (k > 0) L = rk[G_HAB * 64 + c * 8 + i];
+          if (nxt) U = rn[G_HAB * 64 + i * 8 + c];
+        } else {
+          D = rk[G_JB * 64 + (c - 8) * 8 + i];
+          if (nxt) U = rn[G_JA * 64 + (c - 8) * 8 + i];
+        }
+        if (c == 0) {
+          double rx = nv[(NV_GB + i) * K + k] + (nxt ? nv[(NV_GA + i) * K + k + 1] : 0.0);
+          if (i == IA) rx += mu * (id1 - id0);
+          if (i == IM) rx += mu * (id3 - id2);
+          if (i == 7) rx += mu * (id5 - id4);
+          ASC_UNROLL
+          for (int a = 0; a < 4; a++) rx += (last && i == a) ? rt4[a] : 0.0;
+          R = -rx;
+        } else if (c == 1) {
+          R = rk[G_V * 64 + 4 * 8 + i] + (nxt ? rn[G_V * 64 + 3 * 8 + i] : 0.0);
+        } else if (c == 2) {
+          ASC_UNROLL
+          for (int a = 0; a < 4; a++) R += (last && i == a) ? e3g[a] : 0.0;
+        }
+      }
+    } else
     if (rp < 7) {                                             // defect row i: Ja dz_{k-1} + Jb dz_k + Ju du + Jth dth = -c
       const int i = rp;
       if (c < 7) { D = rk[G_JB * 64 + i * 8 + c]; if (k > 0) L = rk[G_JA * 64 + i * 8 + c]; }
@@ -1060,7 +1113,10 @@ __global__ __launch_bounds__(WAVE) void pc_assemble(const ascent_params *params,
   if (l < 32) {
     const int b = l >> 4, cc = l & 15;
     double v = 0.0;
-    if (b == 0) {
+    if (b == 0 && DC) {
+      if (cc < 8) v = rk[G_V * 64 + 4 * 8 + cc] + (nxt ? rn[G_V * 64 + 3 * 8 + cc] : 0.0);
+      else v = rk[G_V * 64 + 2 * 8 + (cc - 8)];
+    } else if (b == 0) {
       if (cc < 7) v = rk[G_V * 64 + 4 * 8 + cc] + (nxt ? rn[G_V * 64 + 3 * 8 + cc] : 0.0);
       else if (cc == 7) v = nv[(NV_P + 8) * K + k];
       else if (cc < 15) v = rk[G_V * 64 + 2 * 8 + (cc - 8)];
@@ -1074,8 +1130,10 @@ __global__ __launch_bounds__(WAVE) void pc_assemble(const ascent_params *params,
 
 // border Schur complement, the step of every node from the PCR solution, bound-multiplier steps, fraction to the boundary,
 // merit bookkeeping; regularisation on the curvature along the step.  One wavefront per NLP, lanes stride over the nodes.
+template <int DC>
 __global__ __launch_bounds__(WAVE) void pc_step(const ascent_params *params, long batch, DGeo g, double *ws, const double *Y,
                                                 const double *bcols, const int *flags, int probe, int *counters) {
+  constexpr int BS = DC ? 16 : PC_BS;
   const long p = blockIdx.x;
   const int l = threadIdx.x, K = g.K;
   double *w = ws + (size_t)p * g.nlp_doubles();
@@ -1087,7 +1145,8 @@ __global__ __launch_bounds__(WAVE) void pc_step(const ascent_params *params, lon
   double nu_pen = sc[X_NUP];
   const double *it = w + g.off_it((int)sc[X_CUR]), *nv = w + g.off_nv();
   double *st = w + g.off_st();
-  const double *Yp = Y + (size_t)p * K * PC_BS * 3, *Bp = bcols + (size_t)p * K * 32;
+  const double *Yp = Y + (size_t)p * K * BS * 3, *Bp = bcols + (size_t)p * K * 32;
+  const double dcw = DC ? params[p].dcost : 0.0, mv = DC ? sc[X_MV] : 0.0;
   double zK[7];
   for (int q = 0; q < 7; q++) zK[q] = it[(O_Z + q) * K + K - 1];
   const Terminal tm = terminal_eval(d, zK);
@@ -1095,8 +1154,8 @@ __global__ __launch_bounds__(WAVE) void pc_step(const ascent_params *params, lon
   double hth = 0.0, s11 = 0.0, s12 = 0.0, s21 = 0.0, s22 = 0.0, t1 = 0.0, t2 = 0.0;
   for (int k = l; k < K; k += WAVE) {
     hth += nv[(NV_P + 9) * K + k];
-    const double *y = Yp + (size_t)k * PC_BS * 3, *b = Bp + (size_t)k * 32;
-    for (int r = 0; r < PC_BS; r++) {
+    const double *y = Yp + (size_t)k * BS * 3, *b = Bp + (size_t)k * 32;
+    for (int r = 0; r < BS; r++) {
       const double bt_ = b[r], bn = b[16 + r], yr = y[r * 3], yt = y[r * 3 + 1], yn = y[r * 3 + 2];
       s11 -= bt_ * yt; s12 -= bt_ * yn; t1 -= bt_ * yr;
       s21 -= bn * yt; s22 -= bn * yn; t2 -= bn * yr;
@@ -1112,12 +1171,12 @@ __global__ __launch_bounds__(WAVE) void pc_step(const ascent_params *params, lon
   int ok = isfinite(dth) && isfinite(dnu3) && !flags[p];
   // ---- the step of every node; bound multipliers; fraction to the boundary ------------------------------------------------
   const double tau = fmax(0.99, 1.0 - mu);
-  double rmax = 0.0, gsum = 0.0, adu = 1.0, cl = 0.0, dx2 = 0.0;
+  double rmax = 0.0, gsum = 0.0, adu = 1.0, cl = 0.0, dx2 = 0.0, gmove = 0.0;
   for (int k = l; k < K; k += WAVE) {
-    const double *y = Yp + (size_t)k * PC_BS * 3;
-    double x[PC_BS];
+    const double *y = Yp + (size_t)k * BS * 3;
+    double x[BS];
     ASC_UNROLL
-    for (int r = 0; r < PC_BS; r++) x[r] = y[r * 3] - y[r * 3 + 1] * dth - y[r * 3 + 2] * dnu3;
+    for (int r = 0; r < BS; r++) x[r] = y[r * 3] - y[r * 3 + 1] * dth - y[r * 3 + 2] * dnu3;
     ASC_UNROLL
     for (int q = 0; q < 7; q++) { st[(O_Z + q) * K + k] = x[q]; st[(O_L + q) * K + k] = x[8 + q]; dx2 += x[q] * x[q]; }
     st[O_U * K + k] = x[7];
@@ -1141,14 +1200,34 @@ __global__ __launch_bounds__(WAVE) void pc_step(const ascent_params *params, lon
     const double *rk = w + g.off_rec() + (size_t)k * NGRID * 64;
     ASC_UNROLL
     for (int q = 0; q < 7; q++) cl += rk[G_V * 64 + q] * (it[(O_L + q) * K + k] + x[8 + q]);
+    if (DC) {       // the slack pair of the movement equation (as in d_newton): d delta from the equation itself
+      const double cu = rk[G_V * 64 + 7], dlu = x[15];
+      double dup = 0.0;
+      if (k > 0) { const double *yp = Yp + (size_t)(k - 1) * BS * 3; dup = yp[7 * 3] - yp[7 * 3 + 1] * dth - yp[7 * 3 + 2] * dnu3; }
+      const double ddel = x[7] - dup + cu;
+      const double pp = it[O_PP * K + k], pn = it[O_PN * K + k], zp = it[O_ZP * K + k], zn = it[O_ZN * K + k], lu = it[O_LU * K + k];
+      const double ip = rcp(pp), in_ = rcp(pn);
+      const double sgp = zp * ip + dw, sgn_ = zn * in_ + dw;
+      double dpp, dpn;
+      if (sgp >= sgn_) { dpp = (dlu - (dcw - mu * ip - lu)) * rcp(sgp); dpn = dpp - ddel; }
+      else { dpn = (-dlu - (dcw - mu * in_ + lu)) * rcp(sgn_); dpp = ddel + dpn; }
+      const double dzp = ip * (mu - zp * dpp) - zp, dzn = in_ * (mu - zn * dpn) - zn;
+      ASC_FTBR(rmax, ip, dpp); ASC_FTBR(rmax, in_, dpn);
+      ASC_FTB(adu, zp, dzp); ASC_FTB(adu, zn, dzn);
+      gsum -= dpp * ip + dpn * in_;
+      gmove += dpp + dpn;
+      dx2 += dpp * dpp + dpn * dpn;
+      cl += cu * (lu + dlu);
+      st[O_LU * K + k] = dlu; st[O_PP * K + k] = dpp; st[O_PN * K + k] = dpn; st[O_ZP * K + k] = dzp; st[O_ZN * K + k] = dzn;
+    }
   }
-  rmax = wmax(rmax); gsum = wsum(gsum); adu = wmin(adu); cl = wsum(cl); dx2 = wsum(dx2);
+  rmax = wmax(rmax); gsum = wsum(gsum); adu = wmin(adu); cl = wsum(cl); dx2 = wsum(dx2); gmove = wsum(gmove);
   // ---- scalars of the step, merit bookkeeping (as d_newton) ---------------------------------------------------------------
   const double is1 = rcp(s.s1), is2 = rcp(s.s2);
   const double sig1 = s.zs1 * is1 + dw, sig2 = s.zs2 * is2 + dw, rs1 = -mu * is1 - s.nu1, rs2 = -mu * is2 - s.nu2;
   double dzKx = 0.0, dzKy = 0.0, dzKvx = 0.0, dzKvy = 0.0;
   {
-    const double *y = Yp + (size_t)(K - 1) * PC_BS * 3;
+    const double *y = Yp + (size_t)(K - 1) * BS * 3;
     dzKx = y[IX * 3] - y[IX * 3 + 1] * dth - y[IX * 3 + 2] * dnu3; dzKy = y[IY * 3] - y[IY * 3 + 1] * dth - y[IY * 3 + 2] * dnu3;
     dzKvx = y[IVX * 3] - y[IVX * 3 + 1] * dth - y[IVX * 3 + 2] * dnu3; dzKvy = y[IVY * 3] - y[IVY * 3 + 1] * dth - y[IVY * 3 + 2] * dnu3;
   }
@@ -1169,7 +1248,7 @@ __global__ __launch_bounds__(WAVE) void pc_step(const ascent_params *params, lon
   ASC_FTB(apr, s.s1, ds.s1); ASC_FTB(apr, s.s2, ds.s2);
   ASC_FTB(adu, s.zlt, ds.zlt); ASC_FTB(adu, s.zut, ds.zut);
   ASC_FTB(adu, s.zs1, ds.zs1); ASC_FTB(adu, s.zs2, ds.zs2);
-  double gd = mu * gsum;
+  double gd = mu * gsum + dcw * gmove;
   gd += ds.th * (1.0 - mu / dl_ + mu / dU) - mu * ds.s1 / s.s1 - mu * ds.s2 / s.s2;
   cl += tm.e3 * (s.nu3 + ds.nu3) + (tm.g1 - s.s1) * (s.nu1 + ds.nu1) + (tm.g2 - s.s2) * (s.nu2 + ds.nu2);
   const double curv = -gd + cl;                 // dx'(W + Sigma + delta_w)dx by the Newton identity
@@ -1192,7 +1271,7 @@ __global__ __launch_bounds__(WAVE) void pc_step(const ascent_params *params, lon
     store_scal(sc, X_D, ds);
     sc[X_NUP] = nu_pen; sc[X_DWL] = dw;
     sc[X_DM] = gd - nu_pen * c1;
-    sc[X_PHI0] = s.th - mu * sl + nu_pen * c1;
+    sc[X_PHI0] = (s.th + mv) - mu * sl + nu_pen * c1;
     sc[X_ALPHA] = apr; sc[X_ADU] = adu;
     if (probe) { sc[X_STATE] = ST_DONE; sc[X_STATUS] = 0; }
     else { sc[X_STATE] = ST_TRIAL; atomicAdd(&counters[0], 1); }
@@ -1329,14 +1408,14 @@ size_t dense_ws_bytes(int K, long batch) {
 // PCR variant: the dense workspace, then two block images, the PCR solution, the border rows, per-NLP flags
 struct PcrWs { double *bt_a, *bt_b, *Y, *bcols; int *flags; };
 static size_t pcr_extra_doubles(int K, long batch) {
-  return (size_t)batch * K * (2 * blocktri_node_doubles() + PC_BS * 3 + 32) + (size_t)batch + 16;
+  return (size_t)batch * K * (2 * blocktri_node_doubles() + PC_BSMAX * 3 + 32) + (size_t)batch + 16;
 }
 size_t dense_pcr_ws_bytes(int K, long batch) { return dense_ws_bytes(K, batch) + pcr_extra_doubles(K, batch) * sizeof(double); }
 static PcrWs pcr_ws(double *ws, int K, long batch) {
   PcrWs q;
   double *base = (double *)((char *)ws + dense_ws_bytes(K, batch));
   const size_t nb = (size_t)batch * K * blocktri_node_doubles();
-  q.bt_a = base; q.bt_b = base + nb; q.Y = base + 2 * nb; q.bcols = q.Y + (size_t)batch * K * PC_BS * 3;
+  q.bt_a = base; q.bt_b = base + nb; q.Y = base + 2 * nb; q.bcols = q.Y + (size_t)batch * K * PC_BSMAX * 3;
   q.flags = (int *)(q.bcols + (size_t)batch * K * 32);
   return q;
 }
@@ -1348,13 +1427,13 @@ static int pcr_newton(const ascent_params *dp, long batch, DGeo g, double *ws, i
   const int K = g.K;
   const PcrWs q = pcr_ws(ws, K, batch);
   DCHK(hipMemsetAsync(q.flags, 0, (size_t)batch * sizeof(int), stream));
-  hipLaunchKernelGGL(pc_assemble, dim3((unsigned)K, (unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g, (const double *)ws, q.bt_a,
-                     q.bcols, blocktri_node_doubles());
+  if (g.dc) hipLaunchKernelGGL(pc_assemble<1>, dim3((unsigned)K, (unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g, (const double *)ws, q.bt_a, q.bcols, blocktri_node_doubles());
+  else hipLaunchKernelGGL(pc_assemble<0>, dim3((unsigned)K, (unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g, (const double *)ws, q.bt_a, q.bcols, blocktri_node_doubles());
   DCHK(hipGetLastError());
-  int rc = blocktri_pcr_assembled(batch, K, PC_BS, PC_NB, q.bt_a, q.bt_b, q.Y, q.flags, stream, err, errlen);
+  int rc = blocktri_pcr_assembled(batch, K, g.dc ? 16 : PC_BS, PC_NB, q.bt_a, q.bt_b, q.Y, q.flags, stream, err, errlen);
   if (rc) return rc;
-  hipLaunchKernelGGL(pc_step, dim3((unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g, ws, (const double *)q.Y,
-                     (const double *)q.bcols, (const int *)q.flags, probe, counters);
+  if (g.dc) hipLaunchKernelGGL(pc_step<1>, dim3((unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g, ws, (const double *)q.Y, (const double *)q.bcols, (const int *)q.flags, probe, counters);
+  else hipLaunchKernelGGL(pc_step<0>, dim3((unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g, ws, (const double *)q.Y, (const double *)q.bcols, (const int *)q.flags, probe, counters);
   DCHK(hipGetLastError());
   return ASCENT_OK;
 }
@@ -1363,7 +1442,6 @@ int dense_run(const ascent_params *dp, long batch, int K, int scheme, int termin
               int max_iter, double tol, double mu0, double *dtraj, double *dtf, int *dstatus, int *diters, double *dblob,
               hipStream_t stream, char *err, size_t errlen, int pcr, int move_penalty) {
   DGeo g{K, scheme, terminal, move_penalty ? 1 : 0};
-  if (g.dc && pcr) { snprintf(err, errlen, "the move penalty is carried by the Riccati form of the dense path only"); return ASCENT_E_ARG; }
   int *counters = (int *)((char *)ws + (size_t)batch * g.nlp_doubles() * sizeof(double));
   static int *host_cnt_dev[64] = {nullptr};
   int dev_ = 0;

@@ -16,7 +16,7 @@ size_t dense_pcr_ws_bytes(int K, long batch);     // with the PCR variant's bloc
 int dense_run(const ascent_params *dp, long batch, int K, int scheme, int terminal, double *ws, const double *dguess, int warm,
               int max_iter, double tol, double mu0, double *dtraj, double *dtf, int *dstatus, int *diters, double *dblob,
               hipStream_t stream, char *err, size_t errlen, int pcr = 0, int move_penalty = 0);
-// move_penalty != 0: the objective gains params.dcost * sum_k |u_k - u_{k-1}| (the reference's MV DCOST, LO:99; Riccati form only).
+// move_penalty != 0: the objective gains params.dcost * sum_k |u_k - u_{k-1}| (the reference's MV DCOST, LO:99; both Newton solvers).
 
 // Parity surface: one Newton step at a caller-supplied iterate (dinertia receives 0 / nonzero), and/or the dense stage
 // records of every step as d_eval leaves them, drecords[batch][K][6][64] (grids Ja, Jb, Haa, Hab, Hbb and the vector grid).

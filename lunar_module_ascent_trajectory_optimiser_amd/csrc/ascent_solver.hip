@@ -945,10 +945,11 @@ bool use_dense_path(const ascent_opts *o, int64_t batch) {
 // parallel cyclic reduction over the collocation nodes (one wavefront per node; ascent_blocktri.hip).  Measured
 // (profiles/r02_c_*): cyclic reduction wins while batch x nodes leaves SIMDs idle, i.e. for a handful of NLPs; the
 // crossover with the serial recursion lies around 100 NLPs.  ASCENT_DENSE_NEWTON=riccati|pcr overrides.
-bool use_pcr_newton(int64_t batch) {
+bool use_pcr_newton(int64_t batch, bool move_penalty = false) {
   const char *e = getenv("ASCENT_DENSE_NEWTON");
   if (e && !strcmp(e, "pcr")) return true;
   if (e && !strcmp(e, "riccati")) return false;
+  if (move_penalty) return batch <= 32;      // 16x16 node blocks: 10.9 vs 19.7 ms at 32 NLPs, 24.4 vs 19.8 at 64 (N=200); one NLP: 3.4 vs 14.2 ms, N=2000: 10.9 vs 166
   return batch <= 64;      // scripts/small_batch_paths.py: 11.9 vs 11.9 ms at 64 NLPs (N=200), 163 vs 176 ms (N=2000); 5.8 vs 11.4 at 16
 }
 
@@ -1141,7 +1142,7 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
   const size_t rows = 21 * (size_t)K + NSC;
   const int lpt = lanes_per_tile(batch);
   const bool dense = use_dense_path(o, batch);
-  const bool pcr = dense && !o->move_penalty && use_pcr_newton(batch);
+  const bool pcr = dense && use_pcr_newton(batch, o->move_penalty != 0);
   const bool persist = !dense && use_persist_path(o, batch);
   const bool split = o->scheme == 1 || o->formulation == 1 || use_split_pipeline(batch);
   // grid levels of the nested iteration, finest first (levels[0] = n_nodes); one level = a plain solve

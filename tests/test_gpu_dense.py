@@ -335,6 +335,15 @@ def test_move_penalty_batch_and_dispatch():
     S2 = S.copy(); S2[:, 15] = 1e-3
     on2 = A.solve_batch(S2, 100, tol=1e-9, move_penalty=True, max_iter=500)
     assert np.all(on2.status == 0) and np.all(tv(on2) < tv(on)) and np.all(on2.tf > on.tf)
+    # both Newton solvers of the dense path carry the penalty: parallel cyclic reduction over the nodes (<= 32 NLPs by default;
+    # 16x16 node blocks: 8 states, 8 multipliers, delta eliminated into the movement equation) and the Riccati recursion
+    for env in ("pcr", "riccati"):
+        os.environ["ASCENT_DENSE_NEWTON"] = env
+        try:
+            rr = A.solve_batch(S, 100, tol=1e-9, move_penalty=True, max_iter=500)
+        finally:
+            del os.environ["ASCENT_DENSE_NEWTON"]
+        assert np.all(rr.status == 0) and np.abs(rr.tf - on.tf).max() <= 2e-9 and np.abs(rr.iters.astype(int) - on.iters).max() <= 4
     # nine orders of magnitude of the weight in one batch: all converge, t_f and the total variation are monotone in it,
     # and the rise of t_f is bounded by the penalty the unpenalised control would pay
     W = np.array([1e-9, 1e-7, 1e-5, 1e-3, 1e-1, 1.0])
