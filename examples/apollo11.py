@@ -120,12 +120,12 @@ if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--no-plots", action="store_true")
     ap.add_argument("--outdir", default=".")
-    ap.add_argument("--dcost", action="store_true", help="apply the MV's DCOST = 1e-5 (Launch_Optimiser.py:99) as an l1 move penalty")
+    ap.add_argument("--no-dcost", action="store_true", help="ignore the MV's DCOST = 1e-5 (Launch_Optimiser.py:99; applied as an l1 move penalty by default)")
     ap.add_argument("--scheme", type=int, default=0, help="0 backward Euler (the reference's NODES=2), 1 trapezoid, 2 Hermite-Simpson")
     a = ap.parse_args()
     model, variables, v_ins = build()
-    if a.dcost:
-        model.options.ASCENT_DCOST = 1
+    if a.no_dcost:
+        model.options.ASCENT_DCOST = 0
     if a.scheme:
         model.options.ASCENT_SCHEME = a.scheme
     model.solve(disp=True)

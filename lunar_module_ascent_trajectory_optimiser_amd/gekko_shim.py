@@ -157,7 +157,7 @@ class _Options:
                              # extensions of this front end (not GEKKO options; real GEKKO ignores unknown attributes):
                              ASCENT_SCHEME=0,      # 0 = NODES=2 backward Euler (the reference), 1 = trapezoid, 2 = Hermite-Simpson
                              ASCENT_TERMINAL=0,    # 0 = the script's terminal speed (:72-78), 1 = the (r_peri, r_apo) ellipse proper
-                             ASCENT_DCOST=0)       # 1 = apply the MV's DCOST (:99) as an l1 move penalty (ascent_opts.move_penalty)
+                             ASCENT_DCOST=1)       # 1 = the MV's DCOST (:99) is applied as an l1 move penalty (ascent_opts.move_penalty), 0 = ignored
 
 
 # ----------------------------------------------------------------------------------------------
@@ -398,11 +398,10 @@ class GEKKO:
         if terminal:
             extra["terminal"] = terminal
         dcost = float(P.dcost)
-        apply_dcost = bool(int(getattr(self.options, "ASCENT_DCOST", 0))) and dcost > 0.0
+        # the script's own MV.DCOST is part of the model it declares: applied (ascent_opts.move_penalty) unless switched off; the
+        # v1 formulation (the angle is the MV) has no move penalty in the library
+        apply_dcost = bool(int(getattr(self.options, "ASCENT_DCOST", 1))) and dcost > 0.0 and not self._formulation
         if apply_dcost:
-            if self._formulation:
-                raise ModelNotRecognised("m.options.ASCENT_DCOST = 1 (the MV's move penalty) is available for the current script's "
-                                         "formulation only (ascent_opts.move_penalty needs formulation 0)")
             extra["move_penalty"] = True
         res = solver(P, nt=nt, tol=tol, max_iter=max_iter, formulation=self._formulation, **extra)
         self.result = res
@@ -410,9 +409,10 @@ class GEKKO:
         if dcost and not apply_dcost and not getattr(GEKKO, "_dcost_warned", False):
             GEKKO._dcost_warned = True
             import warnings
-            warnings.warn(f"MV DCOST = {dcost:g} (Launch_Optimiser.py:99) is not applied by default (m.options.ASCENT_DCOST = 1 "
-                          "applies it: ascent_opts.move_penalty, dense-block path): it shifts the nominal t_f by +1.5e-3 s (3.5e-6 "
-                          "relative; the parity bar is 1e-4) -- see DESIGN.md", stacklevel=2)
+            warnings.warn(f"MV DCOST = {dcost:g} (Launch_Optimiser.py:99) is NOT applied ("
+                          + ("the v1 formulation has no move penalty in libascent" if self._formulation else "m.options.ASCENT_DCOST = 0")
+                          + "): applied, it shifts the nominal t_f by +1.5e-3 s (3.5e-6 relative; the parity bar is 1e-4) -- see "
+                          "DESIGN.md", stacklevel=2)
         if disp:
             names = {0: "backward Euler (NODES=2)", 1: "trapezoid (ASCENT_SCHEME=1)", 2: "Hermite-Simpson (ASCENT_SCHEME=2)"}
             print(" ----------------------------------------------------------------")
@@ -421,7 +421,7 @@ class GEKKO:
                   % (tol, float(self.options.OTOL), float(self.options.RTOL)))
             if dcost:
                 print(" MV DCOST %.1e: %s" % (dcost, "applied (l1 move penalty, ascent_opts.move_penalty)" if apply_dcost
-                                              else "not applied (m.options.ASCENT_DCOST = 1 applies it; effect on t_f: +1.5e-3 s, see DESIGN.md)"))
+                                              else "not applied (effect on t_f: +1.5e-3 s, see DESIGN.md)"))
             print(" iterations: %d   status: %s   objective tf: %.12g" % (int(res.iters[0]), "converged" if ok else f"FAILED ({int(res.status[0])})", float(res.tf[0])))
             print(" ----------------------------------------------------------------")
         if not ok:

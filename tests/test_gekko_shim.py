@@ -21,6 +21,8 @@ def _example():
 
 
 def _oracle_solver(P, nt, tol, max_iter, formulation=0, **kw):
+    # (the C oracle has no move penalty: `move_penalty`, which the front door passes for the script's DCOST, is ignored here --
+    #  its effect on t_f is 3.5e-6, below the 1e-4 these CPU tests compare at; the GPU tests run the penalty itself)
     from oracle import c_oracle
     from lunar_module_ascent_trajectory_optimiser_amd.params import pack
     from lunar_module_ascent_trajectory_optimiser_amd.solver import BatchResult
@@ -206,7 +208,7 @@ def test_solver_options_of_the_script_are_honoured(golden):
     seen = {}
 
     def spy(P, nt, tol, max_iter, formulation=0, **kw):
-        seen.update(tol=tol, kw=kw)
+        seen.clear(); seen.update(tol=tol, kw=kw)
         return _oracle_solver(P, nt, tol, max_iter, formulation, **kw)
 
     ex = _example()
@@ -218,6 +220,16 @@ def test_solver_options_of_the_script_are_honoured(golden):
         warnings.simplefilter("always")
         m.solve(disp=True)
     assert seen["tol"] == 1e-9 and "never looser than 1e-9" in buf.getvalue()
+    # the script's DCOST is part of its model: passed on as the move penalty by default, no warning ...
+    assert seen["kw"].get("move_penalty") is True and "DCOST 1.0e-05: applied" in buf.getvalue()
+    assert not any("DCOST" in str(x.message) for x in w)
+    # ... and reported, once, when it is switched off
+    m.options.ASCENT_DCOST = 0
+    buf = io.StringIO()
+    with redirect_stdout(buf), warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m.solve(disp=True)
+    assert "move_penalty" not in seen["kw"] or not seen["kw"]["move_penalty"]
     assert any("DCOST" in str(x.message) for x in w) and "DCOST 1.0e-05: not applied" in buf.getvalue()
     m.options.OTOL = 1e-11
     m.solve(disp=False)
@@ -232,11 +244,7 @@ def test_solver_options_of_the_script_are_honoured(golden):
         m.solve(disp=False)
     m.options.NODES = 2
     m.options.ASCENT_DCOST = 1                                   # the move penalty reaches the solver as move_penalty=True
-    seen.clear()
-    try:
-        m.solve(disp=False)
-    except TypeError:                                            # (the CPU stand-in of these tests has no move penalty)
-        pass
+    m.solve(disp=False)
     assert seen["kw"].get("move_penalty") is True
 
 
@@ -246,6 +254,7 @@ def test_hermite_simpson_and_ellipse_through_the_front_door():
     reference's problem (435.227 s at 200 nodes) and the insertion into the 17.7 x 88.6 km ellipse proper (440.844 s)."""
     ex = _example()
     m, v, _ = ex.build()
+    m.options.ASCENT_DCOST = 0                                   # (the two anchors below are solutions without the move penalty)
     m.options.ASCENT_SCHEME = 2
     m.solve(disp=False)
     assert abs(m.options.OBJFCNVAL * 470.0 - 435.226762) < 1e-4
@@ -256,8 +265,8 @@ def test_hermite_simpson_and_ellipse_through_the_front_door():
 
 @pytest.mark.gpu
 def test_dcost_through_the_front_door(golden):
-    """m.options.ASCENT_DCOST = 1: the script's own `angledoubledot.DCOST = 1e-5` (Launch_Optimiser.py:99) applied on the HIP
-    path (ascent_opts.move_penalty).  t_f moves by +1.5e-3 s towards Numerical_results.png (20 % of the 7.7e-3 s gap, as the
+    """The script's own `angledoubledot.DCOST = 1e-5` (Launch_Optimiser.py:99) is applied on the HIP path by default
+    (m.options.ASCENT_DCOST = 1 -> ascent_opts.move_penalty; 0 switches it off).  t_f moves by +1.5e-3 s towards Numerical_results.png (20 % of the 7.7e-3 s gap, as the
     numpy oracle measured), the banner says "applied", no warning."""
     import json, os, warnings
     from lunar_module_ascent_trajectory_optimiser_amd.gekko_shim import GEKKO
@@ -265,10 +274,11 @@ def test_dcost_through_the_front_door(golden):
     nominal = [c for c in fx["cases"] if c["nt"] == 200 and c["dcost"] == 1e-5][0]
     ex = _example()
     m, v, _ = ex.build()
+    m.options.ASCENT_DCOST = 0
     m.solve(disp=False)
     t_off = m.options.OBJFCNVAL
     GEKKO._dcost_warned = False
-    m.options.ASCENT_DCOST = 1
+    m.options.ASCENT_DCOST = 1                                   # (the default)
     buf = io.StringIO()
     with redirect_stdout(buf), warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
