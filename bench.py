@@ -322,6 +322,10 @@ def main():
             oc["config1_single_nlp_trapezoid"] = {"ms_per_solve": ms1t, "converged": int((r1t.status == 0).sum()), "iterations": int(r1t.iters[0]),
                                                   "final_time_s": float(r1t.final_time()[0]), "path": A.default_path(1, NT, scheme=1),
                                                   "what": "the same problem with scheme 1 (BASELINE.json configs[1] says 'trapezoidal'; the reference's NODES=2 is backward Euler, SURVEY.md 8a1)"}
+            r1d, ms1d = timed(lambda: A.solve_batch(A.AscentParams(dcost=1e-5), NT, tol=args.tol, move_penalty=True, max_iter=500))
+            oc["config1_single_nlp_with_dcost"] = {"ms_per_solve": ms1d, "converged": int((r1d.status == 0).sum()), "iterations": int(r1d.iters[0]),
+                                                   "final_time_s": float(r1d.final_time()[0]), "path": A.default_path(1, NT, move_penalty=True),
+                                                   "what": "the same problem with the script's MV DCOST = 1e-5 applied as an l1 move penalty (Launch_Optimiser.py:99; ascent_opts.move_penalty = 1)"}
             S4 = np.ascontiguousarray(A.sweep_config4()[:32768])
             r4, ms4 = timed(lambda: A.solve_batch(S4, NT, tol=args.tol, want_traj=False))
             oc["config4_shard0"] = {"value": float((r4.status == 0).sum()) / (ms4 * 1e-3), "unit": "NLPs/s", "ms_per_solve": ms4,
