@@ -31,7 +31,7 @@ typedef struct {            /* 16 doubles, same order as include/ascent.h's asce
       angle_ub, tf_lb, tf_ub, dcost;
 } oparams;
 
-typedef struct { double S, rho0, rhof, vp2, gam, thr, alpha, mrate, ms, M0, T, aub, tlb, tub; } oder;
+typedef struct { double S, rho0, rhof, vp2, gam, thr, alpha, mrate, ms, M0, T, aub, tlb, tub, dcost; } oder;
 
 static void derive(const oparams *p, oder *d) {
   double S = p->r_peri, GM = p->G * p->M;            /* LO:73,107 */
@@ -43,7 +43,7 @@ static void derive(const oparams *p, oder *d) {
   d->alpha = p->ang_acc_max / 3.0;                   /* LO:109 */
   d->mrate = p->mdot / p->fuel_mass;                 /* LO:65 */
   d->ms = p->mass_scalar; d->M0 = p->M0; d->T = p->T_scale;
-  d->aub = p->angle_ub; d->tlb = p->tf_lb; d->tub = p->tf_ub;
+  d->aub = p->angle_ub; d->tlb = p->tf_lb; d->tub = p->tf_ub; d->dcost = p->dcost;
 }
 
 /* accelerations LO:127-136; gradients w.r.t. (x,y,angle,mass); Hessian of px*ax+py*ay
@@ -90,9 +90,13 @@ static void accel(const oder *d, double x, double y, double a, double m, double 
 /* zb per node: zL_angle zU_angle zL_mass zU_mass zL_u zU_u ; sc: th zLth zUth s1 s2 zs1 zs2 nu3 nu1 nu2 */
 enum { S_TH, S_ZLT, S_ZUT, S_S1, S_S2, S_ZS1, S_ZS2, S_NU3, S_NU1, S_NU2, NSC };
 #define BLOB(K) (21 * (K) + NSC)
-typedef struct { int K; double *z, *u, *lam, *zb, *sc; } iter_t;
+/* internal iterates carry five more rows per step behind the external blob -- the move penalty's multiplier and slack pair
+ * (lambda_u, p, n, z_p, z_n; see g_mp below); the external layout (include/ascent.h) does not change */
+#define BLOBX(K) (26 * (K) + NSC)
+typedef struct { int K; double *z, *u, *lam, *zb, *sc, *lu, *pp, *pn, *zp, *zn; } iter_t;
 static void view(double *b, int K, iter_t *it) {
   it->K = K; it->z = b; it->u = b + 7 * K; it->lam = b + 8 * K; it->zb = b + 15 * K; it->sc = b + 21 * K;
+  it->lu = b + 21 * K + NSC; it->pp = it->lu + K; it->pn = it->pp + K; it->zp = it->pn + K; it->zn = it->zp + K;
 }
 
 typedef struct { double G[8], H[10], F[7], E[4]; } stage_t;
@@ -108,6 +112,15 @@ static __thread int g_scheme = 0;
  *       angle row becomes algebraic,  angle_k - (angle_ub/2)(u_k + 1) = 0  with u in [-1,1] (so angle in
  *       [0, angle_ub], the MV's bounds), it has no coupling to angle_{k-1}, and angledot stays 0. */
 static __thread int g_form = 0;
+/* Move penalty (LO:99, angledoubledot.DCOST = 1e-5; MV_TYPE = 0, LO:29): 1 = the objective is tf + dcw * sum_k |u_k - u_{k-1}|,
+ * u_{-1} = the MV's initial value (0; formulation 1: the angle is the MV, angle_{-1} = 0, i.e. u_{-1} = -1, and the weight on
+ * u is dcost * angle_ub/2), as the l1 term APMonitor documents for DCOST: a slack pair per step,
+ *   u_k - u_{k-1} - p_k + n_k = 0 (multiplier lambda_u,k),  p, n >= 0,  cost dcw (p_k + n_k).
+ * The control then couples to the control of the step before: u_k becomes the eighth state of a stage, the stage's scalar
+ * control is delta_k = p_k - n_k, and its two bounded slacks reduce to one pivot (kkt_solve_mp). */
+static __thread int g_mp = 0;
+static double mp_weight(const oder *d) { return g_form == 1 ? d->dcost * 0.5 * d->aub : d->dcost; }
+static double mp_u_init(void) { return g_form == 1 ? -1.0 : 0.0; }
 
 /* rhs of the scaled ODEs without tf*T (LO:114-123) */
 static void rhs_f(const oder *d, const double *z, double u, double ax, double ay, double F[7]) {
@@ -203,6 +216,9 @@ typedef struct {
   double rth, sth, e3g[7], g1g[7], g2g[7], sig[2], rs[2];
   double *step;     /* blob */
   double *trial, *ctrial;
+  /* move penalty: movement equations cu (K), the reduced slack pair's curvature Rd and gradient gdl (K), the 8-state
+   * feedback gains kap8 (8K), the stage control's step ddel (K), the regularisation of the last assemble */
+  double *cu, *Rd, *gdl, *kap8, *ddel, *cutrial, dw;
 } work_t;
 
 static work_t *work_new(int K) {
@@ -212,13 +228,21 @@ static work_t *work_new(int K) {
   w->Q = calloc(49 * K, 8); w->R = calloc(K, 8); w->gth = calloc(7 * K, 8); w->gu = calloc(K, 8);
   w->rz = calloc(7 * K, 8); w->ru = calloc(K, 8); w->c = calloc(7 * K + 3, 8);
   w->kap = calloc(7 * K, 8); w->kap0 = calloc(3 * K, 8); w->Dp = calloc(K, 8);
-  w->step = calloc(BLOB(K), 8); w->trial = calloc(BLOB(K), 8); w->ctrial = calloc(7 * K + 3, 8);
+  w->step = calloc(BLOBX(K), 8); w->trial = calloc(BLOBX(K), 8); w->ctrial = calloc(7 * K + 3, 8);
+  w->cu = calloc(K, 8); w->Rd = calloc(K, 8); w->gdl = calloc(K, 8); w->kap8 = calloc(8 * K, 8); w->ddel = calloc(K, 8);
+  w->cutrial = calloc(K, 8);
   return w;
 }
 static void work_free(work_t *w) {
   free(w->st); free(w->Q); free(w->R); free(w->gth); free(w->gu); free(w->rz); free(w->ru);
   free(w->c); free(w->kap); free(w->kap0); free(w->Dp); free(w->step); free(w->trial);
-  free(w->ctrial); free(w);
+  free(w->ctrial); free(w->cu); free(w->Rd); free(w->gdl); free(w->kap8); free(w->ddel); free(w->cutrial); free(w);
+}
+
+/* movement equations of the move penalty: cu_k = u_k - u_{k-1} - p_k + n_k */
+static double u_prev_move(const iter_t *it, int k) { return it->u[k] - (k ? it->u[k - 1] : mp_u_init()) - it->pp[k] + it->pn[k]; }
+static void move_constraints(int K, const iter_t *it, double *cu) {
+  for (int k = 0; k < K; k++) cu[k] = it->u[k] - (k ? it->u[k - 1] : mp_u_init()) - it->pp[k] + it->pn[k];
 }
 
 /* evaluate everything the Newton system needs at the iterate (mu enters the barrier gradient) */
@@ -288,6 +312,22 @@ static void assemble(const oder *d, work_t *w, const iter_t *it, double mu, doub
     Q[i * 7 + j] += w->sig[0] * w->g1g[i] * w->g1g[j] + w->sig[1] * w->g2g[i] * w->g2g[j];
   w->rth = rth - mu / (th - d->tlb) + mu / (d->tub - th);
   w->sth = it->sc[S_ZLT] / (th - d->tlb) + it->sc[S_ZUT] / (d->tub - th) + dw;
+  w->dw = dw;
+  if (g_mp) {
+    /* the control is a state now: its stationarity row gains the multipliers of its two movement equations; the stage's
+     * control delta_k = p_k - n_k carries the reduced slack pair: with Sigma_p = z_p/p + dw, Sigma_n = z_n/n + dw and the
+     * stationarity residuals r_p = dcw - mu/p - lambda_u, r_n = dcw - mu/n + lambda_u:
+     *   curvature Rd = 1/(1/Sigma_p + 1/Sigma_n),  gradient gdl = Rd (r_p/Sigma_p - r_n/Sigma_n),  d lambda_u = Rd d delta + gdl */
+    const double dcw = mp_weight(d);
+    move_constraints(K, it, w->cu);
+    for (int k = 0; k < K; k++) {
+      w->ru[k] += it->lu[k] - (k + 1 < K ? it->lu[k + 1] : 0.0);
+      const double ip = 1.0 / it->pp[k], in = 1.0 / it->pn[k];
+      const double isp = 1.0 / (it->zp[k] * ip + dw), isn = 1.0 / (it->zn[k] * in + dw);
+      w->Rd[k] = 1.0 / (isp + isn);
+      w->gdl[k] = w->Rd[k] * ((dcw - mu * ip - it->lu[k]) * isp - (dcw - mu * in + it->lu[k]) * isn);
+    }
+  }
 }
 
 /* Newton step by the backward (Riccati) / forward / adjoint sweeps with the (dtheta, dnu3) border.
@@ -372,7 +412,7 @@ static int kkt_solve(const oder *d, work_t *w, const iter_t *it, double mu) {
   if (!(det < 0.0)) return 1;
   double dth = (b1 * a22 - a12 * b2) / det, dnu3 = (a11 * b2 - a12 * b1) / det;
   iter_t st; view(w->step, K, &st);
-  memset(w->step, 0, BLOB(K) * 8);
+  memset(w->step, 0, BLOBX(K) * 8);
   st.sc[S_TH] = dth; st.sc[S_NU3] = dnu3;
   double zero[7] = {0};
   for (int k = 0; k < K; k++) {             /* forward */
@@ -428,6 +468,175 @@ static int kkt_solve(const oder *d, work_t *w, const iter_t *it, double mu) {
   return 0;
 }
 
+/* ---- move penalty: the same sweeps with the control as the eighth state --------------------------------------------
+ * Extended state xh = (z, u); the step's extended Jacobian is Ah = [[A, -bu e_IB], [0, 1]] (the control enters defect row
+ * IB with coefficient -bu; row 7 is the movement equation), the stage's scalar control delta enters row 7 with -1. */
+static void solveA8(const stage_t *s, double cs, double bu, int IB, const double *r, double *v) {
+  double t[7]; memcpy(t, r, 56);
+  t[IB] += bu * r[7];
+  solveA(s, cs, t, v);
+  v[7] = r[7];
+}
+static void solveAT8(const stage_t *s, double cs, double bu, int IB, const double *r, double *v) {
+  solveAT(s, cs, r, v);
+  v[7] = r[7] + bu * v[IB];
+}
+
+static int kkt_solve_mp(const oder *d, work_t *w, const iter_t *it, double mu) {
+  int K = w->K; double hT = w->h * d->T, th = it->sc[S_TH], dt = hT * th, be = dt * d->alpha;
+  const double cs = g_scheme == 1 ? 0.5 * dt : dt;
+  const int IB = g_form == 1 ? IA : IW;
+  be = g_form == 1 ? 0.5 * d->aub : be;
+  const double dcw = mp_weight(d), dw = w->dw;
+  double P[64] = {0}, p[3][8] = {{0}};
+  double S10 = 0, S11 = 0, S12 = 0, S20 = 0, S22 = 0;
+  for (int k = K - 1; k >= 0; k--) {
+    const stage_t *s = w->st + k;
+    const double *Q = w->Q + 49 * k;
+    double N[64], Y[64], M[64], col[8], out[8];
+    if (g_scheme == 1 && k + 1 < K) {        /* P <- Abar' P Abar, p <- Abar' p; the control passes through unchanged */
+      double T[64];
+      for (int c = 0; c < 8; c++) {
+        double e[8] = {0}, ae[8]; e[c] = 1.0; abar_mul(s->G, cs, e, ae); ae[7] = e[7];
+        for (int i = 0; i < 8; i++) { double a = 0; for (int l = 0; l < 8; l++) a += P[i * 8 + l] * ae[l]; T[i * 8 + c] = a; }
+      }
+      for (int c = 0; c < 8; c++) {
+        for (int i = 0; i < 8; i++) col[i] = T[i * 8 + c];
+        abart_mul(s->G, cs, col, out); out[7] = col[7];
+        for (int i = 0; i < 8; i++) P[i * 8 + c] = out[i];
+      }
+      for (int i = 0; i < 8; i++) for (int j = i + 1; j < 8; j++) { double a = 0.5 * (P[i * 8 + j] + P[j * 8 + i]); P[i * 8 + j] = P[j * 8 + i] = a; }
+      for (int j = 0; j < 3; j++) { abart_mul(s->G, cs, p[j], out); out[7] = p[j][7]; memcpy(p[j], out, 64); }
+    }
+    if (g_form == 1 && k + 1 < K) {
+      for (int i = 0; i < 8; i++) { P[IA * 8 + i] = 0.0; P[i * 8 + IA] = 0.0; }
+      for (int j = 0; j < 3; j++) p[j][IA] = 0.0;
+    }
+    memcpy(N, P, sizeof N);
+    for (int i = 0; i < 7; i++) for (int j = 0; j < 7; j++) N[i * 8 + j] += Q[i * 7 + j];
+    N[63] += w->R[k];                        /* the control's bound terms + delta_w */
+    for (int c = 0; c < 8; c++) {
+      for (int i = 0; i < 8; i++) col[i] = N[i * 8 + c];
+      solveAT8(s, cs, be, IB, col, out);
+      for (int i = 0; i < 8; i++) Y[i * 8 + c] = out[i];
+    }
+    for (int r = 0; r < 8; r++) {
+      solveAT8(s, cs, be, IB, Y + 8 * r, out);
+      for (int i = 0; i < 8; i++) M[r * 8 + i] = out[i];
+    }
+    for (int i = 0; i < 8; i++) for (int j = i + 1; j < 8; j++) {
+      double a = 0.5 * (M[i * 8 + j] + M[j * 8 + i]); M[i * 8 + j] = M[j * 8 + i] = a;
+    }
+    double D = w->Rd[k] + M[63];
+    if (!(D > 0.0)) return 1;
+    w->Dp[k] = D;
+    double *kap = w->kap8 + 8 * k;
+    for (int i = 0; i < 8; i++) kap[i] = M[i * 8 + 7] / D;
+    for (int i = 0; i < 8; i++) for (int j = 0; j < 8; j++) P[i * 8 + j] = M[i * 8 + j] - D * kap[i] * kap[j];
+    double rc[3][8], q[3][8], k0[3];
+    for (int j = 0; j < 3; j++) {
+      double n[8], nt[8], ruj;
+      for (int i = 0; i < 7; i++) {
+        double rzj = j == 0 ? -w->rz[7 * k + i] : j == 1 ? -w->gth[7 * k + i] : (k == K - 1 ? -w->e3g[i] : 0.0);
+        n[i] = rzj + p[j][i];
+        rc[j][i] = j == 0 ? -w->c[7 * k + i] : j == 1 ? hT * s->F[i] : 0.0;
+      }
+      n[7] = (j == 0 ? -w->ru[k] : j == 1 ? -w->gu[k] : 0.0) + p[j][7];
+      rc[j][7] = j == 0 ? -w->cu[k] : 0.0;
+      ruj = j == 0 ? -w->gdl[k] : 0.0;
+      solveAT8(s, cs, be, IB, n, nt);
+      k0[j] = (nt[7] + ruj) / D;
+      for (int i = 0; i < 8; i++) q[j][i] = nt[i] - M[i * 8 + 7] * k0[j];
+      for (int i = 0; i < 8; i++) {
+        double a = 0; for (int l = 0; l < 8; l++) a += P[i * 8 + l] * rc[j][l];
+        p[j][i] = q[j][i] - a;
+      }
+      w->kap0[3 * k + j] = k0[j];
+    }
+#define BIL8(i, j) ({ double a_ = D * k0[i] * k0[j]; \
+      for (int l = 0; l < 8; l++) { a_ += 0.5 * (rc[i][l] * (q[j][l] + p[j][l]) + rc[j][l] * (q[i][l] + p[i][l])); } \
+      a_; })
+    S10 += BIL8(1, 0); S11 += BIL8(1, 1); S12 += BIL8(1, 2); S20 += BIL8(2, 0); S22 += BIL8(2, 2);
+#undef BIL8
+  }
+  double a11 = w->sth - S11, a12 = -S12, a22 = -S22;
+  double b1 = -w->rth + S10, b2 = -w->c[7 * K] + S20;
+  double det = a11 * a22 - a12 * a12;
+  if (!(det < 0.0)) return 1;
+  double dth = (b1 * a22 - a12 * b2) / det, dnu3 = (a11 * b2 - a12 * b1) / det;
+  iter_t st; view(w->step, K, &st);
+  memset(w->step, 0, BLOBX(K) * 8);
+  st.sc[S_TH] = dth; st.sc[S_NU3] = dnu3;
+  double zero[7] = {0};
+  for (int k = 0; k < K; k++) {             /* forward */
+    const stage_t *s = w->st + k;
+    const double *zp = k ? st.z + 7 * (k - 1) : zero, *kap = w->kap8 + 8 * k;
+    double xi[8], azp[7], xo[8], dd = w->kap0[3 * k] + w->kap0[3 * k + 1] * dth + w->kap0[3 * k + 2] * dnu3;
+    if (g_scheme == 1 && k > 0) abar_mul((s - 1)->G, cs, zp, azp); else memcpy(azp, zp, 56);
+    if (g_form == 1) azp[IA] = 0.0;
+    for (int i = 0; i < 7; i++) xi[i] = azp[i] - w->c[7 * k + i] + hT * s->F[i] * dth;
+    xi[7] = (k ? st.u[k - 1] : 0.0) - w->cu[k];
+    for (int i = 0; i < 8; i++) dd -= kap[i] * xi[i];
+    w->ddel[k] = dd;
+    xi[7] += dd;
+    solveA8(s, cs, be, IB, xi, xo);
+    memcpy(st.z + 7 * k, xo, 56);
+    st.u[k] = xo[7];
+  }
+  for (int k = K - 1; k >= 0; k--) {        /* adjoint: the seven defect multipliers do not see the movement equations */
+    const stage_t *s = w->st + k;
+    const double *Q = w->Q + 49 * k, *dz = st.z + 7 * k;
+    double r[7];
+    for (int i = 0; i < 7; i++) {
+      double a = -w->rz[7 * k + i] - w->gth[7 * k + i] * dth - (k == K - 1 ? w->e3g[i] * dnu3 : 0.0);
+      for (int l = 0; l < 7; l++) a -= Q[i * 7 + l] * dz[l];
+      r[i] = a;
+    }
+    if (k + 1 < K) {
+      double t[7];
+      if (g_scheme == 1) abart_mul(s->G, cs, st.lam + 7 * (k + 1), t); else memcpy(t, st.lam + 7 * (k + 1), 56);
+      if (g_form == 1) t[IA] = 0.0;
+      for (int i = 0; i < 7; i++) r[i] += t[i];
+    }
+    solveAT(s, cs, r, st.lam + 7 * k);
+  }
+  /* the movement multiplier from the stage control's own stationarity row, then the slack pair: the slack with the larger
+   * curvature from its own row (well conditioned), the other one from delta = p - n (its own row divides a difference of two
+   * nearly equal numbers by a curvature that vanishes for an inactive slack) */
+  for (int k = 0; k < K; k++) {
+    const double pp = it->pp[k], pn = it->pn[k], zp = it->zp[k], zn = it->zn[k], lu = it->lu[k], dd = w->ddel[k];
+    const double dlu = w->Rd[k] * dd + w->gdl[k];
+    const double sgp = zp / pp + dw, sgn = zn / pn + dw;
+    double dpp, dpn;
+    if (sgp >= sgn) { dpp = (dlu - (dcw - mu / pp - lu)) / sgp; dpn = dpp - dd; }
+    else { dpn = (-dlu - (dcw - mu / pn + lu)) / sgn; dpp = dd + dpn; }
+    st.lu[k] = dlu; st.pp[k] = dpp; st.pn[k] = dpn;
+    st.zp[k] = (mu - zp * dpp) / pp - zp; st.zn[k] = (mu - zn * dpn) / pn - zn;
+  }
+  const double *dzK = st.z + 7 * (K - 1);
+  double ds1 = w->c[7 * K + 1], ds2 = w->c[7 * K + 2];
+  for (int i = 0; i < 7; i++) { ds1 += w->g1g[i] * dzK[i]; ds2 += w->g2g[i] * dzK[i]; }
+  st.sc[S_S1] = ds1; st.sc[S_S2] = ds2;
+  st.sc[S_NU1] = w->sig[0] * ds1 + w->rs[0]; st.sc[S_NU2] = w->sig[1] * ds2 + w->rs[1];
+  double s1 = it->sc[S_S1], s2 = it->sc[S_S2];
+  st.sc[S_ZS1] = mu / s1 - it->sc[S_ZS1] - it->sc[S_ZS1] / s1 * ds1;
+  st.sc[S_ZS2] = mu / s2 - it->sc[S_ZS2] - it->sc[S_ZS2] / s2 * ds2;
+  double dl = th - d->tlb, dU = d->tub - th;
+  st.sc[S_ZLT] = mu / dl - it->sc[S_ZLT] - it->sc[S_ZLT] / dl * dth;
+  st.sc[S_ZUT] = mu / dU - it->sc[S_ZUT] + it->sc[S_ZUT] / dU * dth;
+  for (int k = 0; k < K; k++) {
+    const double *z = it->z + 7 * k, *zb = it->zb + 6 * k, *dz = st.z + 7 * k;
+    double *dzb = st.zb + 6 * k, u = it->u[k], du = st.u[k];
+    double lo[3] = {z[IA], z[IM], u + 1.0}, up[3] = {d->aub - z[IA], 1.0 - z[IM], 1.0 - u};
+    double dx[3] = {dz[IA], dz[IM], du};
+    for (int b = 0; b < 3; b++) {
+      dzb[2 * b] = mu / lo[b] - zb[2 * b] - zb[2 * b] / lo[b] * dx[b];
+      dzb[2 * b + 1] = mu / up[b] - zb[2 * b + 1] + zb[2 * b + 1] / up[b] * dx[b];
+    }
+  }
+  return 0;
+}
+
 /* barrier objective */
 static double barrier(const oder *d, const iter_t *it, double mu) {
   int K = it->K; double th = it->sc[S_TH];
@@ -435,6 +644,11 @@ static double barrier(const oder *d, const iter_t *it, double mu) {
   for (int k = 0; k < K; k++) {
     const double *z = it->z + 7 * k; double u = it->u[k];
     sl += log(z[IA]) + log(d->aub - z[IA]) + log(z[IM]) + log(1.0 - z[IM]) + log(u + 1.0) + log(1.0 - u);
+  }
+  if (g_mp) {
+    double mv = 0.0;
+    for (int k = 0; k < K; k++) { mv += it->pp[k] + it->pn[k]; sl += log(it->pp[k]) + log(it->pn[k]); }
+    return (th + mp_weight(d) * mv) - mu * sl;
   }
   return th - mu * sl;
 }
@@ -467,7 +681,15 @@ static double kkt_error(const oder *d, work_t *w, const iter_t *it, double mu) {
     }
     for (int i = 0; i < 7; i++) rd = fmax(rd, fabs(r[i]));
     double u = it->u[k];
-    const double ru = (g_form == 1 ? -0.5 * d->aub * l[IA] : -dt * d->alpha * l[IW]) - zb[4] + zb[5];
+    double ru = (g_form == 1 ? -0.5 * d->aub * l[IA] : -dt * d->alpha * l[IW]) - zb[4] + zb[5];
+    if (g_mp) {
+      const double dcw = mp_weight(d);
+      ru += it->lu[k] - (k + 1 < K ? it->lu[k + 1] : 0.0);
+      rd = fmax(rd, fmax(fabs(dcw - it->lu[k] - it->zp[k]), fabs(dcw + it->lu[k] - it->zn[k])));
+      comp = fmax(comp, fmax(fabs(it->pp[k] * it->zp[k] - mu), fabs(it->pn[k] * it->zn[k] - mu)));
+      zsum += it->zp[k] + it->zn[k]; l1 += fabs(it->lu[k]);
+      cc = fmax(cc, fabs(u_prev_move(it, k)));
+    }
     rd = fmax(rd, fabs(ru));
     if (k == 0) memset(g_err_rt, 0, sizeof g_err_rt);
     for (int i = 0; i < 7; i++) g_err_rt[i] = fmax(g_err_rt[i], fabs(r[i]));
@@ -485,7 +707,7 @@ static double kkt_error(const oder *d, work_t *w, const iter_t *it, double mu) {
   comp = fmax(comp, fmax(fabs(it->sc[S_S1] * it->sc[S_ZS1] - mu), fabs(it->sc[S_S2] * it->sc[S_ZS2] - mu)));
   l1 += fabs(it->sc[S_NU3]) + fabs(it->sc[S_NU1]) + fabs(it->sc[S_NU2]);
   zsum += it->sc[S_ZLT] + it->sc[S_ZUT] + it->sc[S_ZS1] + it->sc[S_ZS2];
-  double sd = fmax(100.0, (l1 + zsum) / (double)(7 * K + 3 + 6 * K + 4)) / 100.0;
+  double sd = fmax(100.0, (l1 + zsum) / (double)(7 * K + 3 + 6 * K + 4 + (g_mp ? 3 * K : 0))) / 100.0;
   g_err_rd = rd; g_err_cc = cc; g_err_comp = comp; g_err_sd = sd;
   return fmax(fmax(rd / sd, cc), comp / sd);
 }
@@ -530,7 +752,7 @@ static int solve_one(const oparams *prm, int nt, int max_iter, double tol, int w
   iter_t it, tr, st; view(blob, K, &it); view(w->trial, K, &tr); view(w->step, K, &st);
   const int asked_warm = warm;
   if (warm && !(it.sc[S_TH] > 0.0)) warm = 0;
-  if (!warm) { memset(blob, 0, BLOB(K) * 8); initial_guess(&d, K, w->h, &it); }
+  if (!warm) { memset(blob, 0, BLOBX(K) * 8); initial_guess(&d, K, w->h, &it); }
   const double s1g = it.sc[S_S1], s2g = it.sc[S_S2];
   it.sc[S_S1] = it.sc[S_S2] = 0.0;
   constraints(&d, K, w->h, &it, w->c);
@@ -550,6 +772,14 @@ static int solve_one(const oparams *prm, int nt, int max_iter, double tol, int w
     it.sc[S_ZLT] = it.sc[S_ZUT] = it.sc[S_ZS1] = it.sc[S_ZS2] = 1.0;
     memset(it.lam, 0, 7 * K * 8); it.sc[S_NU3] = it.sc[S_NU1] = it.sc[S_NU2] = 0.0;
   }
+  const double dcw = g_mp ? mp_weight(&d) : 0.0;
+  if (g_mp) {      /* slacks of the movement equations around the guess's own movement; multipliers that zero their stationarity rows */
+    const double eps = warm ? 1e-4 : 1e-2;
+    for (int k = 0; k < K; k++) {
+      const double dl = it.u[k] - (k ? it.u[k - 1] : mp_u_init());
+      it.lu[k] = 0.0; it.pp[k] = fmax(dl, 0.0) + eps; it.pn[k] = fmax(-dl, 0.0) + eps; it.zp[k] = it.zn[k] = dcw;
+    }
+  }
   double mu = (asked_warm && !warm) ? g_mu0 : mu0 > 0.0 ? mu0 : (warm ? 1e-4 : g_mu0), nu_pen = 1.0, dw_last = 0.0;
   int status = ST_MAXITER, iters = 0, nreg = 0;
   for (int iter = 0; iter < max_iter; iter++) {
@@ -564,7 +794,7 @@ static int solve_one(const oparams *prm, int nt, int max_iter, double tol, int w
     double dw = 0.0; int fail = 0;
     for (;;) {
       assemble(&d, w, &it, mu, dw);
-      if (kkt_solve(&d, w, &it, mu) == 0) break;
+      if ((g_mp ? kkt_solve_mp(&d, w, &it, mu) : kkt_solve(&d, w, &it, mu)) == 0) break;
       /* inertia correction: first one of a solve 1e-2, later ones a third of the last successful value, x10 while wrong */
       dw = dw == 0.0 ? (dw_last == 0.0 ? 1e-2 : fmax(1e-4, dw_last / 3.0)) : dw * 10.0;
       nreg++;
@@ -591,8 +821,14 @@ static int solve_one(const oparams *prm, int nt, int max_iter, double tol, int w
       gd += dz[IA] * (-mu / z[IA] + mu / (d.aub - z[IA])) + dz[IM] * (-mu / z[IM] + mu / (1.0 - z[IM]))
           + du * (-mu / (u + 1.0) + mu / (1.0 - u));
     }
+    if (g_mp) for (int k = 0; k < K; k++) {
+      FTB(apr, it.pp[k], st.pp[k]); FTB(apr, it.pn[k], st.pn[k]);
+      FTB(adu, it.zp[k], st.zp[k]); FTB(adu, it.zn[k], st.zn[k]);
+      gd += dcw * (st.pp[k] + st.pn[k]) - mu * (st.pp[k] / it.pp[k] + st.pn[k] / it.pn[k]);
+    }
     /* l1 merit (Nocedal & Wright eq. 18.36); curvature from the Newton identity dx'H dx = -gd + c'(lam+dlam) */
     double c1 = 0, cl = 0;
+    if (g_mp) for (int k = 0; k < K; k++) { c1 += fabs(w->cu[k]); cl += w->cu[k] * (it.lu[k] + st.lu[k]); }
     for (int i = 0; i < 7 * K; i++) { c1 += fabs(w->c[i]); cl += w->c[i] * (it.lam[i] + st.lam[i]); }
     for (int j = 0; j < 3; j++) {
       static const int nu_ix[3] = {S_NU3, S_NU1, S_NU2};
@@ -603,11 +839,13 @@ static int solve_one(const oparams *prm, int nt, int max_iter, double tol, int w
     double Dm = gd - nu_pen * c1, phi0 = barrier(&d, &it, mu) + nu_pen * c1, alpha = apr;
     int ok = 0;
     for (int ls = 0; ls < 40; ls++) {
-      memcpy(w->trial, blob, BLOB(K) * 8);
+      memcpy(w->trial, blob, BLOBX(K) * 8);
       for (int i = 0; i < 8 * K; i++) w->trial[i] += alpha * w->step[i];
+      if (g_mp) for (int k = 0; k < K; k++) { tr.pp[k] += alpha * st.pp[k]; tr.pn[k] += alpha * st.pn[k]; }
       tr.sc[S_TH] += alpha * st.sc[S_TH]; tr.sc[S_S1] += alpha * st.sc[S_S1]; tr.sc[S_S2] += alpha * st.sc[S_S2];
       constraints(&d, K, w->h, &tr, w->ctrial);
       double ct = 0; for (int i = 0; i < 7 * K + 3; i++) ct += fabs(w->ctrial[i]);
+      if (g_mp) { move_constraints(K, &tr, w->cutrial); for (int k = 0; k < K; k++) ct += fabs(w->cutrial[k]); }
       double phit = barrier(&d, &tr, mu) + nu_pen * ct;
       if (isfinite(phit) && phit <= phi0 + 1e-8 * alpha * Dm + 10 * 2.220446049250313e-16 * fabs(phi0)) { ok = 1; break; }
       alpha *= 0.5;
@@ -620,6 +858,10 @@ static int solve_one(const oparams *prm, int nt, int max_iter, double tol, int w
     for (int i = 0; i < 8 * K; i++) blob[i] += alpha * w->step[i];
     for (int i = 0; i < 7 * K; i++) it.lam[i] += alpha * st.lam[i];
     for (int i = 0; i < 6 * K; i++) it.zb[i] += adu * st.zb[i];
+    if (g_mp) for (int k = 0; k < K; k++) {
+      it.lu[k] += alpha * st.lu[k]; it.pp[k] += alpha * st.pp[k]; it.pn[k] += alpha * st.pn[k];
+      it.zp[k] += adu * st.zp[k]; it.zn[k] += adu * st.zn[k];
+    }
     it.sc[S_TH] += alpha * st.sc[S_TH]; it.sc[S_S1] += alpha * st.sc[S_S1]; it.sc[S_S2] += alpha * st.sc[S_S2];
     it.sc[S_NU3] += alpha * st.sc[S_NU3]; it.sc[S_NU1] += alpha * st.sc[S_NU1]; it.sc[S_NU2] += alpha * st.sc[S_NU2];
     it.sc[S_ZLT] += adu * st.sc[S_ZLT]; it.sc[S_ZUT] += adu * st.sc[S_ZUT];
@@ -633,6 +875,7 @@ static int solve_one(const oparams *prm, int nt, int max_iter, double tol, int w
       double *z = it.z + 7 * k, *zb = it.zb + 6 * k, u = it.u[k];
       CLIP(zb[0], z[IA]); CLIP(zb[1], d.aub - z[IA]); CLIP(zb[2], z[IM]); CLIP(zb[3], 1.0 - z[IM]);
       CLIP(zb[4], u + 1.0); CLIP(zb[5], 1.0 - u);
+      if (g_mp) { CLIP(it.zp[k], it.pp[k]); CLIP(it.zn[k], it.pn[k]); }
     }
     iters = iter + 1;
   }
@@ -656,6 +899,7 @@ void oracle_accel(const double *params, int n, const double *x, const double *y,
 /* equality-constraint values at an iterate blob */
 void oracle_set_scheme(int scheme) { g_scheme = scheme == 1 ? 1 : 0; }
 void oracle_set_formulation(int form) { g_form = form == 1 ? 1 : 0; }
+void oracle_set_move_penalty(int on) { g_mp = on ? 1 : 0; }
 int oracle_get_scheme(void) { return g_scheme; }
 
 void oracle_constraints(const double *params, int nt, const double *blob, double *c) {
@@ -669,9 +913,19 @@ int oracle_newton_step(const double *params, int nt, const double *blob, double 
                        double *step) {
   int K = nt - 1; oder d; derive((const oparams *)params, &d);
   work_t *w = work_new(K); iter_t it; view((double *)blob, K, &it);
+  double *xb = 0;
+  if (g_mp) {      /* the external blob has no slack rows: they are set around the iterate's own movement, as a warm start does */
+    xb = malloc(BLOBX(K) * 8); memcpy(xb, blob, BLOB(K) * 8); view(xb, K, &it);
+    const double dcw = mp_weight(&d);
+    for (int k = 0; k < K; k++) {
+      const double dl = it.u[k] - (k ? it.u[k - 1] : mp_u_init());
+      it.lu[k] = 0.0; it.pp[k] = fmax(dl, 0.0) + 1e-4; it.pn[k] = fmax(-dl, 0.0) + 1e-4; it.zp[k] = it.zn[k] = dcw;
+    }
+  }
   assemble(&d, w, &it, mu, delta_w);
-  int rc = kkt_solve(&d, w, &it, mu);
+  int rc = g_mp ? kkt_solve_mp(&d, w, &it, mu) : kkt_solve(&d, w, &it, mu);
   memcpy(step, w->step, BLOB(K) * 8);
+  free(xb);
   work_free(w);
   return rc;
 }
@@ -734,7 +988,7 @@ static int solve_nested(const oparams *prm, int nt, int max_iter, double tol, do
     if (depth_out) *depth_out = 0;
     return solve_one(prm, nt, max_iter, tol, 0, 0.0, blob, iters_out, 0);
   }
-  double *bc = malloc(BLOB(nc - 1) * 8);
+  double *bc = malloc(BLOBX(nc - 1) * 8);
   int itc = 0, itf = 0, depth_c = 0;
   const int stc = solve_nested(prm, nc, max_iter, fmax(tol, NESTED_COARSE_TOL), tol_finest, coarse > 0 ? -1 : 0, bc, &itc, &depth_c);
   int warm = 0;
@@ -762,7 +1016,7 @@ int oracle_solve_batch(const double *params, int batch, int nt, int max_iter, do
   int K = nt - 1;
   for (int b = 0; b < batch; b++) {
     const oparams *prm = (const oparams *)(params + 16 * b);
-    double *blob = malloc(BLOB(K) * 8);
+    double *blob = malloc(BLOBX(K) * 8);
     int iters = 0, st;
     if (guess_blob_or_null) {
       memcpy(blob, guess_blob_or_null + (size_t)b * BLOB(K), BLOB(K) * 8);

@@ -58,12 +58,19 @@ def blob_size(nt):
     return lib().oracle_blob_size(nt)
 
 
-def newton_step(params16, nt, blob, mu, delta_w, scheme=0, formulation=0):
+def newton_step(params16, nt, blob, mu, delta_w, scheme=0, formulation=0, move_penalty=False):
+    """One Newton step of the barrier problem at `blob`.  move_penalty: with the l1 move penalty (LO:99); the slack pairs,
+    which the external blob does not carry, are set around the iterate's own movement (p = max(du, 0) + 1e-4,
+    n = max(-du, 0) + 1e-4, z_p = z_n = dcw, lambda_u = 0), as every warm start sets them."""
     L = lib()
     L.oracle_set_scheme(int(scheme))
     L.oracle_set_formulation(int(formulation))
+    L.oracle_set_move_penalty(int(bool(move_penalty)))
     step = np.zeros_like(blob)
-    rc = L.oracle_newton_step(_p(params16), nt, _p(blob), C.c_double(mu), C.c_double(delta_w), _p(step))
+    try:
+        rc = L.oracle_newton_step(_p(params16), nt, _p(blob), C.c_double(mu), C.c_double(delta_w), _p(step))
+    finally:
+        L.oracle_set_move_penalty(0)
     return rc, step
 
 
@@ -89,11 +96,13 @@ def accel(params16, x, y, a, m, px, py):
 
 
 def solve_batch(params, nt=200, max_iter=300, tol=1e-9, guess_blob=None, want_blob=False, scheme=0, formulation=0,
-                coarse_nodes=0, warm_start=1, mu_init=0.0):
+                coarse_nodes=0, warm_start=1, mu_init=0.0, move_penalty=False):
     """params: (batch,16).  Returns dict(traj (batch,10,nt), tf, status, iters[, blob]).
     Cold starts use the nested iteration (coarse_nodes: 0 automatic, -1 single grid, > 0 explicit coarse grid);
     with guess_blob (batch, blob) it is a warm start (1 primal, 2 primal-dual; mu_init <= 0: 1e-4).
-    iters counts the iterations of all grid levels."""
+    iters counts the iterations of all grid levels.  move_penalty: the reference's MV DCOST (LO:99) as an l1 term with the
+    `dcost` of each parameter row (off: dcost is ignored)."""
+    lib().oracle_set_move_penalty(int(bool(move_penalty)))
     lib().oracle_set_scheme(int(scheme))
     lib().oracle_set_formulation(int(formulation))
     lib().oracle_set_coarse_nodes(int(coarse_nodes))
@@ -111,6 +120,7 @@ def solve_batch(params, nt=200, max_iter=300, tol=1e-9, guess_blob=None, want_bl
                              _p(g) if g is not None else None, _p(traj), _p(tf),
                              status.ctypes.data_as(_ip), iters.ctypes.data_as(_ip),
                              _p(blob) if blob is not None else None)
+    lib().oracle_set_move_penalty(0)
     out = dict(traj=traj, tf=tf, status=status, iters=iters)
     if want_blob:
         out["blob"] = blob
