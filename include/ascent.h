@@ -179,6 +179,11 @@ enum ascent_path { ASCENT_PATH_AUTO = 0, ASCENT_PATH_FUSED = 1, ASCENT_PATH_SPLI
 /* Which kernels ascent_solve_batch runs for a batch of this size with these options (and the environment overrides):
  * an ascent_path value, never ASCENT_PATH_AUTO.  No device work. */
 int ascent_default_path(int64_t batch, const ascent_opts *o);
+/* Diagnostic (no device work): the persistent kernel's device workspace for a solve of `batch` NLPs with these options.
+ * Returns the number of grid levels of the nested iteration (>= 1) or a negative code; out4[0] = bytes allocated,
+ * out4[1] = bytes the finest level's kernels use from offset 0, out4[2] = offset of the second region (the two regions
+ * alternate between the levels; 0 with one level), out4[3] = bytes the largest level living in the second region uses. */
+int ascent_workspace_layout(int64_t batch, const ascent_opts *o, int64_t *out4);
 int ascent_eval_nodes_path(const ascent_params *p, int64_t batch, const ascent_opts *o,
                            const double *iterate, double *defects, double *jac_blocks,
                            double *hess_blocks, int device_id, int path);

@@ -164,7 +164,7 @@ __global__ __launch_bounds__(WAVE) void d_init(const ascent_params *params, long
   for (int r = 0; r < NIT; r++) st[r * K + k] = 0.0;
   if (g.dc) {      // slacks of the movement equation around the guess's own movement; multipliers that zero their stationarity rows
     double up = (k > 0 && warm) ? guess[(7L * K + k - 1) * batch + p] : 0.0;
-    if (k > 0) up = push_in(up, -1.0, 1.0);
+    if (k > 0 && !probe) up = push_in(up, -1.0, 1.0);
     const double dl = u - up, eps = warm ? 1e-4 : 1e-2, dc = params[p].dcost;
     it[O_LU * K + k] = 0.0;
     it[O_PP * K + k] = fmax(dl, 0.0) + eps; it[O_PN * K + k] = fmax(-dl, 0.0) + eps;
@@ -1485,8 +1485,8 @@ int dense_run(const ascent_params *dp, long batch, int K, int scheme, int termin
 
 int dense_probe(const ascent_params *dp, long batch, int K, int scheme, int terminal, double *ws, const double *diterate,
                 const double *dmu, const double *ddw, bool step_too, double *dstep, int *dinertia, double *drecords,
-                hipStream_t stream, char *err, size_t errlen, int pcr) {
-  DGeo g{K, scheme, terminal};
+                hipStream_t stream, char *err, size_t errlen, int pcr, int move_penalty) {
+  DGeo g{K, scheme, terminal, move_penalty ? 1 : 0};
   int *counters = (int *)((char *)ws + (size_t)batch * g.nlp_doubles() * sizeof(double));
   const dim3 ngrid((unsigned)((K + WAVE - 1) / WAVE), (unsigned)batch);
   hipLaunchKernelGGL(d_init, ngrid, dim3(WAVE), 0, stream, dp, batch, g, ws, diterate, 2, 0.1, 1, dmu);

@@ -22,7 +22,7 @@ int dense_run(const ascent_params *dp, long batch, int K, int scheme, int termin
 // records of every step as d_eval leaves them, drecords[batch][K][6][64] (grids Ja, Jb, Haa, Hab, Hbb and the vector grid).
 int dense_probe(const ascent_params *dp, long batch, int K, int scheme, int terminal, double *ws, const double *diterate,
                 const double *dmu, const double *ddw, bool step_too, double *dstep, int *dinertia, double *drecords,
-                hipStream_t stream, char *err, size_t errlen, int pcr = 0);
+                hipStream_t stream, char *err, size_t errlen, int pcr = 0, int move_penalty = 0);
 
 // Kepler-exact coast arc from every NLP's burnout state (scaled x, y, xdot, ydot: dstate4[4][batch]) to the next apoapsis:
 // dcoast[4][nc+1][batch], dtheta2[batch] (duration / T_scale), dapsides[2][batch] (periapsis, apoapsis altitude in m).

@@ -44,32 +44,46 @@ using namespace ascent;
 namespace {
 
 constexpr int NPW = 4, CH = 16;                 // NLPs per wavefront, nodes per chunk
-constexpr int O_Z = 0, O_U = 7, O_L = 8, O_ZB = 15, NIT = 21;
-constexpr int R_IT = 0, R_ST = 2 * NIT, R_KA = 3 * NIT, R_K0 = R_KA + 7, NROWS = R_K0 + 3;      // rows of an NLP's node arrays
-// LDS stage rows (one chunk): blocks of the factorisation; the forward / adjoint phases reuse the area
-constexpr int S_G = 0, S_E = 8, S_H = 12, S_F = 22, S_C = 29, S_RZ = 36, S_GT = 43, S_SC = 50, S_ROWS = 55;
-constexpr int S_KA = 36, S_K0 = 43;             // forward phase: gains (loaded from HBM) where the factor phase keeps rz / gt
-constexpr int S_R = 12;                         // adjoint phase: right-hand side where the factor phase keeps H
+constexpr int O_Z = 0, O_U = 7, O_L = 8, O_ZB = 15;
+constexpr int O_LU = 21, O_PP = 22, O_PN = 23, O_ZP = 24, O_ZN = 25;      // move penalty only: lambda_u, p, n, z_p, z_n
+// Rows of an NLP's node arrays: two iterate buffers, the step, the feedback gains of the factorisation.  MP = 1: with the l1 move
+// penalty (ascent_opts.move_penalty, the reference's angledoubledot.DCOST, Launch_Optimiser.py:99) the control is the eighth
+// state of a stage and an iterate carries five more rows per node.
+template <int MP>
+struct Lay {
+  static constexpr int NS = 7 + MP, NIT = 21 + 5 * MP;
+  static constexpr int R_IT = 0, R_ST = 2 * NIT, R_KA = 3 * NIT, R_K0 = R_KA + NS, NROWS = R_K0 + 3;
+  // LDS stage rows (one chunk): blocks of the factorisation; the forward / adjoint phases reuse the area
+  // (MP: the mass row of hT F is a constant of the NLP and the barrier gradients are folded into rz, so that the stage stays within
+  //  56 rows -- with 12 output rows and the small arrays 40 672 bytes per wavefront: four wavefronts per CU, as without the penalty)
+  static constexpr int S_G = 0, S_E = 8, S_H = 12, S_F = 22, S_C = S_F + 7 - MP, S_RZ = S_C + NS, S_GT = S_RZ + NS, S_SC = S_GT + NS;
+  static constexpr int S_ROWS = MP ? 56 : 55;        // (MP: S_SC + 3 = 55 in the factor phase; the forward phase's 7 lanes x 8 rows)
+  static constexpr int OUT_ROWS = 11 + MP;
+  static_assert(S_SC + (MP ? 3 : 5) <= S_ROWS, "stage rows");
+};
+constexpr int R_IT = 0;
 constexpr int LDW = 65;                         // row stride in doubles: odd, so that the 16 rows a sweep step gathers hit 16 banks
-constexpr int OUT_ROWS = 11;
 enum {
   X_STATE, X_ITERS, X_STATUS, X_CUR, X_FIRST, X_LS, X_MU, X_NUP, X_DW, X_DWL, X_ALPHA, X_ADU, X_PHI0, X_DM, X_C1, X_SL,
   X_RTH, X_DTH, X_DNU3, X_SIG1, X_SIG2, X_RS1, X_RS2, X_CG1, X_CG2,
   X_ITB,                     // iterations spent on the coarser grids of the nested iteration
   X_PROBE, X_PDW,            // parity probe: one round at the caller's iterate, mu and delta_w, then stop
   X_TEVAL,                   // the trial point of the next round has been evaluated already (by the adjoint phase)
-  X_P,                       // 9 reduced partials of that trial point: rd cinf pmin pmax l1 zsum rth c1 sl
-  X_PEND = X_P + 8,
+  X_P,                       // 10 reduced partials of that trial point: rd cinf pmin pmax l1 zsum rth c1 sl mv
+  X_PEND = X_P + 9,
+  X_MV,                      // move penalty: sum of the slack pairs of the iterate (its part of the objective, without the weight)
   X_S,                       // 10 scalars of the iterate
-  X_T = X_S + 10,            // 10 trial scalars
-  X_D = X_T + 10,            // 10 step scalars
+  X_D = X_S + 10,            // 10 step scalars
   NSCAL = X_D + 10
 };
 enum { ST_TRIAL = 0, ST_FACTOR = 1, ST_FACTORED = 2, ST_DONE = 3 };
 
 struct PGeo {
-  int K, Kp, nch, form;
-  __host__ __device__ size_t nlp_doubles() const { return (size_t)NROWS * Kp + NSCAL; }
+  int K, Kp, nch, form, mp;
+  __host__ __device__ int nit() const { return mp ? Lay<1>::NIT : Lay<0>::NIT; }
+  __host__ __device__ int r_st() const { return 2 * nit(); }
+  __host__ __device__ int nrows() const { return mp ? Lay<1>::NROWS : Lay<0>::NROWS; }
+  __host__ __device__ size_t nlp_doubles() const { return (size_t)nrows() * Kp + NSCAL; }
 };
 
 template <int SRC>
@@ -126,6 +140,33 @@ ASC_DEV Scal trial_scal(const Der &d, const Scal &s, const Scal &ds, double alph
 // ==============================================================================================================
 // p_init / p_transfer / p_finish: starting points and results.  Lane = (NLP, node) in p_init and p_transfer.
 // ==============================================================================================================
+// Move penalty: the slack pair of the movement equation u_k - u_{k-1} = p_k - n_k at a starting point -- around the guess's own
+// movement (u, up: the pushed controls of nodes k and k-1), multipliers that zero the pair's stationarity rows
+// (d_init of the dense-block path, solve_one of the C restatement)
+ASC_DEV void start_move(double *w, int Kp, int k, double u, double up, bool warm, double dcw) {
+  const double dl = u - up, eps = warm ? 1e-4 : 1e-2;
+  w[(R_IT + O_LU) * Kp + k] = 0.0;
+  w[(R_IT + O_PP) * Kp + k] = fmax(dl, 0.0) + eps;
+  w[(R_IT + O_PN) * Kp + k] = fmax(-dl, 0.0) + eps;
+  w[(R_IT + O_ZP) * Kp + k] = dcw;
+  w[(R_IT + O_ZN) * Kp + k] = dcw;
+}
+// The reduced slack pair of a stage: with Sigma_p = z_p/p + dw, Sigma_n = z_n/n + dw and the stationarity residuals
+// r_p = dcw - mu/p - lambda_u, r_n = dcw - mu/n + lambda_u the stage's control delta = p - n has curvature
+// Rd = 1/(1/Sigma_p + 1/Sigma_n) and gradient gdl = Rd (r_p/Sigma_p - r_n/Sigma_n);  d lambda_u = Rd d delta + gdl.
+// (One function for every phase that needs the pair: the same bits everywhere, see the note on contraction above.)
+struct MovePivot { double ip, in_, sgp, sgn, rp, rn, Rd, gdl; };
+ASC_DEV MovePivot move_pivot(double pp, double pn, double zp, double zn, double lu, double dcw, double mu, double dw) {
+  MovePivot m;
+  m.ip = rcp(pp); m.in_ = rcp(pn);
+  m.sgp = zp * m.ip + dw; m.sgn = zn * m.in_ + dw;
+  m.rp = dcw - mu * m.ip - lu; m.rn = dcw - mu * m.in_ + lu;
+  const double isp = rcp(m.sgp), isn = rcp(m.sgn);
+  m.Rd = rcp(isp + isn);
+  m.gdl = m.Rd * (m.rp * isp - m.rn * isn);
+  return m;
+}
+
 // The starting point at node kk: the built-in straight-line guess (warm == 0) or the caller's / the coarser grid's values in
 // z, l, u, zb, pushed into the interior (warm 1: primal only, warm 2: primal-dual; a probe takes them as they are)
 ASC_DEV void start_node(const Der &d, int K, int kk, int warm, bool probe, int form, double *z, double *l, double *zb, double &u) {
@@ -198,8 +239,13 @@ __global__ __launch_bounds__(WAVE) void p_init(const ascent_params *params, long
   }
   start_node(d, K, kk, warm, probe, g.form, z, l, zb, u);
   store_start(w, Kp, k, z, l, zb, u);
+  if (g.mp) {
+    double up = (kk > 0 && warm) ? guess[(7L * K + kk - 1) * batch + p] : 0.0;
+    if (kk > 0 && !probe) up = push_in(up, -1.0, 1.0);
+    start_move(w, Kp, k, u, up, warm != 0, params[p].dcost);
+  }
   if (k != K - 1) return;
-  double *sc = w + (size_t)NROWS * Kp;
+  double *sc = w + (size_t)g.nrows() * Kp;
   Scal s;
   if (warm) {
     const double *gs = guess + (21L * K) * batch + p;
@@ -225,13 +271,22 @@ __global__ __launch_bounds__(WAVE) void p_transfer(const ascent_params *params, 
   const long p = blockIdx.y;
   const int k = blockIdx.x * WAVE + threadIdx.x, Kc = gc.K, Kf = gf.K, Kpc = gc.Kp, Kpf = gf.Kp;
   if (k >= Kpf) return;
-  const double *wc = wsc + (size_t)p * gc.nlp_doubles(), *scc = wc + (size_t)NROWS * Kpc;
+  const double *wc = wsc + (size_t)p * gc.nlp_doubles(), *scc = wc + (size_t)gc.nrows() * Kpc;
   double *wf = wsf + (size_t)p * gf.nlp_doubles();
   const Der d = derive(params[p]);
   const int warm = (int)scc[X_STATUS] == ASCENT_CONVERGED ? 2 : 0;
-  const double *ic = wc + (size_t)((int)scc[X_CUR] * NIT) * Kpc;
-  double z[7], l[7], zb[6], u = 0.0;
+  const double *ic = wc + (size_t)((int)scc[X_CUR] * gc.nit()) * Kpc;
+  double z[7], l[7], zb[6], u = 0.0, up = 0.0;
   const int kk = k < Kf ? k : Kf - 1;
+  if (warm && gf.mp && kk > 0) {      // the prolonged control of the node before (for the slack pair of this node's movement)
+    const double x = (double)kk / (double)Kf * (double)Kc;
+    int j = (int)x;
+    if (j > Kc - 1) j = Kc - 1;
+    const double wt = x - (double)j;
+    const int ja = j ? j - 1 : 0;
+    const double a = ic[O_U * Kpc + ja], b = ic[O_U * Kpc + j];
+    up = push_in(fma(wt, b - a, a), -1.0, 1.0);
+  }
   if (warm) {
     const double x = (double)(kk + 1) / (double)Kf * (double)Kc;
     int j = (int)x;
@@ -255,8 +310,9 @@ __global__ __launch_bounds__(WAVE) void p_transfer(const ascent_params *params, 
   }
   start_node(d, Kf, kk, warm, false, gf.form, z, l, zb, u);
   store_start(wf, Kpf, k, z, l, zb, u);
+  if (gf.mp) start_move(wf, Kpf, k, u, up, warm != 0, params[p].dcost);
   if (k != Kf - 1) return;
-  double *sc = wf + (size_t)NROWS * Kpf;
+  double *sc = wf + (size_t)gf.nrows() * Kpf;
   Scal s;
   if (warm) s = lds_scal(scc, X_S);
   start_scal(d, warm, false, z, s);
@@ -277,9 +333,9 @@ __global__ __launch_bounds__(WAVE * FIN_WAVES) void p_finish(const ascent_params
   if (p >= batch) return;
   const int c = blockIdx.x, K = g.K, Kp = g.Kp, nt = K + 1;
   const double *w = ws + (size_t)p * g.nlp_doubles();
-  const double *sc = w + (size_t)NROWS * Kp;
+  const double *sc = w + (size_t)g.nrows() * Kp;
   const Der d = derive(params[p]);
-  const double *it = w + (size_t)((int)sc[X_CUR] * NIT) * Kp;
+  const double *it = w + (size_t)((int)sc[X_CUR] * g.nit()) * Kp;
   if (c == 0 && threadIdx.y == 0) {
     const Scal s = lds_scal(sc, X_S);
     tf_out[p] = s.th;
@@ -330,7 +386,7 @@ __global__ __launch_bounds__(WAVE) void p_probe_out(long batch, PGeo g, const do
   const int k = blockIdx.x * WAVE + threadIdx.x, K = g.K, Kp = g.Kp;
   if (k >= K) return;
   const double *w = ws + (size_t)p * g.nlp_doubles();
-  const double *sc = w + (size_t)NROWS * Kp, *stp = w + (size_t)R_ST * Kp;
+  const double *sc = w + (size_t)g.nrows() * Kp, *stp = w + (size_t)g.r_st() * Kp;
   const bool ok = (int)sc[X_STATE] == ST_TRIAL;
   if (k == 0) {
     inertia[p] = ok ? 0 : 1;
@@ -351,7 +407,9 @@ __global__ __launch_bounds__(WAVE) void p_probe_out(long batch, PGeo g, const do
 // ==============================================================================================================
 struct NodeIn {      // what a node evaluation reads: node k of the iterate, the state of node k-1, the multipliers of node k+1
   double z[7], zp[7], l[7], ln[7], zb[6], u;
+  double up, lu, lun, pp, pn, zpp, zpn;      // move penalty only: u_{k-1}, lambda_u of nodes k and k+1, the slack pair and its multipliers
 };
+template <int MP = 0>
 ASC_DEV void load_node(const double *it, int Kp, int K, int k, NodeIn &n) {
   ASC_UNROLL
   for (int i = 0; i < 7; i++) {
@@ -363,6 +421,12 @@ ASC_DEV void load_node(const double *it, int Kp, int K, int k, NodeIn &n) {
   n.u = it[O_U * Kp + k];
   ASC_UNROLL
   for (int b = 0; b < 6; b++) n.zb[b] = it[(O_ZB + b) * Kp + k];
+  if constexpr (MP) {
+    n.up = k > 0 ? it[O_U * Kp + k - 1] : 0.0;
+    n.lu = it[O_LU * Kp + k];
+    n.lun = k + 1 < K ? it[O_LU * Kp + k + 1] : 0.0;
+    n.pp = it[O_PP * Kp + k]; n.pn = it[O_PN * Kp + k]; n.zpp = it[O_ZP * Kp + k]; n.zpn = it[O_ZN * Kp + k];
+  }
 }
 
 // Rows xdot and ydot of A^-1, A = I - dt df/dz (see solveA in ascent_device.hpp).  The other rows follow from them:
@@ -378,22 +442,24 @@ ASC_DEV void ainv_vrows(const double *G, const double *E, double dt, double *rvx
 
 // Partial sums of the merit function and the KKT error over the nodes a lane evaluates
 struct Part {
-  double rd, cinf, pmin, pmax, l1, zsum, rth, c1, sl;
-  ASC_DEV void clear() { rd = 0.0; cinf = 0.0; pmin = 1e300; pmax = -1e300; l1 = 0.0; zsum = 0.0; rth = 0.0; c1 = 0.0; sl = 0.0; }
+  double rd, cinf, pmin, pmax, l1, zsum, rth, c1, sl, mv;
+  ASC_DEV void clear() { rd = 0.0; cinf = 0.0; pmin = 1e300; pmax = -1e300; l1 = 0.0; zsum = 0.0; rth = 0.0; c1 = 0.0; sl = 0.0; mv = 0.0; }
+  template <int MP = 0>
   ASC_DEV void reduce16() {
     rd = gmax16(rd); cinf = gmax16(cinf); pmin = gmin16(pmin); pmax = gmax16(pmax);
     l1 = gsum16(l1); zsum = gsum16(zsum); rth = gsum16(rth); c1 = gsum16(c1); sl = gsum16(sl);
+    if constexpr (MP) mv = gsum16(mv);
   }
 };
 struct TrialCtx {       // what the trial point of an NLP needs besides the node data
-  double alpha, adu, mlo, mhi, dt, be, hT;
+  double alpha, adu, mlo, mhi, dt, be, hT, dcw;
   bool first;
   Scal stt;
 };
 
 // The trial point x + alpha dx at node k (iterate n, step dn), stored into the other iterate buffer, and its pieces of the
 // l1 merit function and of the KKT error (Launch_Optimiser.py:114-136 evaluated once, with first derivatives).
-template <int SCHEME, int FORM>
+template <int SCHEME, int FORM, int MP = 0>
 ASC_DEV void trial_node(const Der &d, int K, int Kp, int k, const NodeIn &n, const NodeIn &dn, const TrialCtx &t, bool live,
                         double *in, Part &P) {
   const double alpha = t.alpha;
@@ -416,6 +482,26 @@ ASC_DEV void trial_node(const Der &d, int K, int Kp, int k, const NodeIn &n, con
     in[O_U * Kp + k] = u;
     ASC_UNROLL
     for (int b = 0; b < 6; b++) in[(O_ZB + b) * Kp + k] = zb[b];
+  }
+  double lu = 0.0, lun = 0.0;
+  if constexpr (MP) {      // the movement equation of the step, its slack pair and their rows of the KKT error
+    const double up = n.up + alpha * dn.up, pp = n.pp + alpha * dn.pp, pn = n.pn + alpha * dn.pn;
+    lu = n.lu + alpha * dn.lu; lun = n.lun + alpha * dn.lun;
+    const double ip = rcp(pp), in_ = rcp(pn);
+    const double zpp = t.first ? n.zpp : fmin(fmax(n.zpp + t.adu * dn.zpp, t.mlo * ip), t.mhi * ip);
+    const double zpn = t.first ? n.zpn : fmin(fmax(n.zpn + t.adu * dn.zpn, t.mlo * in_), t.mhi * in_);
+    if (live) { in[O_LU * Kp + k] = lu; in[O_PP * Kp + k] = pp; in[O_PN * Kp + k] = pn; in[O_ZP * Kp + k] = zpp; in[O_ZN * Kp + k] = zpn; }
+    const double cu = u - up - pp + pn;
+    P.c1 += fabs(cu);
+    P.cinf = fmax(P.cinf, fabs(cu));
+    P.l1 += fabs(lu);
+    P.rd = fmax(P.rd, fmax(fabs(t.dcw - lu - zpp), fabs(t.dcw + lu - zpn)));
+    const double prp = pp * zpp, prn = pn * zpn;
+    P.pmin = fmin(P.pmin, fmin(prp, prn)); P.pmax = fmax(P.pmax, fmax(prp, prn));
+    P.zsum += zpp + zpn;
+    P.mv += pp + pn;
+    const double ps = pp * pn;
+    P.sl += ps > 0.0 ? log(ps) : NAN;
   }
   // (scheme 1, the trapezoid with the control held over the step: defect z_k - z_{k-1} - dt/2 [f(z_k,u_k) + f(z_{k-1},u_k)]; node k then
   //  carries the multipliers of steps k and k+1 in its stationarity row, each with half the step)
@@ -460,7 +546,9 @@ ASC_DEV void trial_node(const Der &d, int K, int Kp, int k, const NodeIn &n, con
   }
   ASC_UNROLL
   for (int i = 0; i < 7; i++) P.rd = fmax(P.rd, fabs(r[i]));
-  P.rd = fmax(P.rd, fabs((FORM == 1 ? -0.5 * d.aub * l[IA] : -t.be * l[IW]) - zb[4] + zb[5]));
+  double ruv = (FORM == 1 ? -0.5 * d.aub * l[IA] : -t.be * l[IW]) - zb[4] + zb[5];
+  if constexpr (MP) ruv += lu - lun;
+  P.rd = fmax(P.rd, fabs(ruv));
   ASC_UNROLL
   for (int b = 0; b < 6; b++) { const double pr = dist[b] * zb[b]; P.pmin = fmin(P.pmin, pr); P.pmax = fmax(P.pmax, pr); P.zsum += zb[b]; }
   const double pa = dist[0] * dist[1], pm = dist[2] * dist[3], pu = dist[4] * dist[5];
@@ -477,11 +565,16 @@ ASC_DEV void trial_node(const Der &d, int K, int Kp, int k, const NodeIn &n, con
 #define PROF_END do { } while (0)
 #endif
 
-template <int SCHEME, int FORM>
+template <int SCHEME, int FORM, int MP = 0>
 __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, long batch, PGeo g, double *ws, int max_iter, double tol) {
-  __shared__ double stage[S_ROWS * LDW];
-  __shared__ double outb[OUT_ROWS * LDW];
-  __shared__ double lds_t[NPW][7][7];
+  using L = Lay<MP>;
+  constexpr int NS = L::NS, NIT = L::NIT, R_ST = L::R_ST, R_KA = L::R_KA, R_K0 = L::R_K0, NROWS = L::NROWS;
+  constexpr int S_G = L::S_G, S_E = L::S_E, S_H = L::S_H, S_F = L::S_F, S_C = L::S_C, S_RZ = L::S_RZ, S_GT = L::S_GT, S_SC = L::S_SC;
+  constexpr int RL = NS;                                // the first of the three right-hand-side lanes of the factorisation sweep
+  static_assert(FORM == 0 || MP == 0, "the move penalty is carried for the current formulation only");
+  __shared__ double stage[L::S_ROWS * LDW];
+  __shared__ double outb[L::OUT_ROWS * LDW];
+  __shared__ double lds_t[NPW][NS][NS];
   __shared__ double lds_d[NPW][3][8];                   // (row 2 stays zero)
   __shared__ double lsc[NPW][NSCAL];
   __shared__ double lds_c[NPW][8];                      // adjoint phase: the multiplier step of the first node of the chunk above
@@ -502,6 +595,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
   const int col = grp * 16 + role;                      // this lane's column of the LDS stage in node-parallel phases
   const double hT = (1.0 / K) * d.T;
   constexpr int IB = FORM == 1 ? IA : IW;          // the defect row the control enters (v1: the algebraic angle row)
+  const double dcw = MP ? params[pc].dcost : 0.0;  // weight of the l1 move penalty
 
   PROF_DECL
   for (int round = 0; round < 64 * (max_iter + 2); round++) {
@@ -522,22 +616,22 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
       Part P;
       if (sc[X_TEVAL] != 0.0) {             // evaluated by the adjoint phase of the previous round
         P.rd = sc[X_P + 0]; P.cinf = sc[X_P + 1]; P.pmin = sc[X_P + 2]; P.pmax = sc[X_P + 3]; P.l1 = sc[X_P + 4];
-        P.zsum = sc[X_P + 5]; P.rth = sc[X_P + 6]; P.c1 = sc[X_P + 7]; P.sl = sc[X_P + 8];
+        P.zsum = sc[X_P + 5]; P.rth = sc[X_P + 6]; P.c1 = sc[X_P + 7]; P.sl = sc[X_P + 8]; P.mv = sc[X_P + 9];
       } else {
         TrialCtx t;
-        t.alpha = alpha; t.adu = adu; t.mlo = mlo; t.mhi = mhi; t.dt = dt; t.be = be; t.hT = hT; t.first = first; t.stt = stt;
+        t.alpha = alpha; t.adu = adu; t.mlo = mlo; t.mhi = mhi; t.dt = dt; t.be = be; t.hT = hT; t.first = first; t.stt = stt; t.dcw = dcw;
         P.clear();
         for (int c = 0; c < nch; c++) {
           const int k = c * CH + role;
           if (k < K) {
             NodeIn n, dn;
-            load_node(ic, Kp, K, k, n);
+            load_node<MP>(ic, Kp, K, k, n);
             if (first) dn = NodeIn{};             // (no step yet; the step rows are not initialised)
-            else load_node(stp, Kp, K, k, dn);
-            trial_node<SCHEME, FORM>(d, K, Kp, k, n, dn, t, live, in, P);
+            else load_node<MP>(stp, Kp, K, k, dn);
+            trial_node<SCHEME, FORM, MP>(d, K, Kp, k, n, dn, t, live, in, P);
           }
         }
-        P.reduce16();
+        P.template reduce16<MP>();
       }
       double rd = P.rd, cinf = P.cinf, pmin = P.pmin, pmax = P.pmax, l1 = P.l1, zsum = P.zsum;
       const double rth = 1.0 + P.rth, c1 = P.c1, sl = P.sl;
@@ -547,7 +641,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
       bool accepted = true;
       if (!first) {
         const double phi0 = sc[X_PHI0], Dm = sc[X_DM];
-        const double phit = stt.th - mu * sl + nu_pen * c1;
+        const double phit = (MP ? stt.th + dcw * P.mv : stt.th) - mu * sl + nu_pen * c1;
         if (!(isfinite(phit) && phit <= phi0 + 1e-8 * alpha * Dm + 2.220446049250313e-15 * fabs(phi0))) {
           accepted = false;
           const int ls = (int)sc[X_LS] + 1;
@@ -572,7 +666,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
         e.pmin = pmin; e.pmax = pmax;
         l1 += fabs(stt.nu3) + fabs(stt.nu1) + fabs(stt.nu2);
         zsum += stt.zlt + stt.zut + stt.zs1 + stt.zs2;
-        e.sd = fmax(100.0, (l1 + zsum) / (double)(13 * K + 7)) * 0.01;
+        e.sd = fmax(100.0, (l1 + zsum) / (double)((MP ? 16 : 13) * K + 7)) * 0.01;
         int status = -1;
         const bool probe = sc[X_PROBE] != 0.0;
         if (probe) { }
@@ -596,6 +690,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
           put_scal(sc, X_S, stt);
           sc[X_CUR] = 1 - cur; sc[X_FIRST] = 0.0; sc[X_ITERS] = iters; sc[X_LS] = 0.0; sc[X_C1] = c1; sc[X_SL] = sl; sc[X_RTH] = rth;
           sc[X_MU] = mu2; sc[X_NUP] = nu_pen; sc[X_DW] = probe ? sc[X_PDW] : 0.0; sc[X_STATE] = nstate; sc[X_TEVAL] = 0.0;
+          if (MP) sc[X_MV] = P.mv;
           if (status >= 0) sc[X_STATUS] = status;
         }
       }
@@ -613,34 +708,40 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
       const double ha = 0.5 * d.aub, bu = FORM == 1 ? ha : be;          // (v1: angle = ha (u + 1), the control enters the angle row)
       const double hTc = SCHEME == 1 ? 0.5 * hT : hT;
       // what this lane gathers from a step's blocks for row i of its vector (factor phase), as in q_factor_wide
-      int grow[7];
-      double gsgn[7];
+      // (MP: eight column lanes -- the control is the eighth state, its bound terms S_SC+0 its diagonal entry -- and the
+      //  right-hand-side lanes 8-10; the stage's scalar control is delta = p - n with the reduced pair's curvature and gradient)
+      int grow[NS];
+      double gsgn[NS];
       {
-        constexpr int hmap[7] = {0, 1, -1, -1, 2, -1, 3};
+        constexpr int hmap[8] = {0, 1, -1, -1, 2, -1, 3, -1};
         constexpr int hrow[4][4] = {{0, 1, 2, 3}, {1, 4, 5, 6}, {2, 5, 7, 8}, {3, 6, 8, 9}};
         ASC_UNROLL
-        for (int i = 0; i < 7; i++) {
+        for (int i = 0; i < NS; i++) {
           int row = S_H; double sgn = 0.0;
           if (role < 7) {
             ASC_UNROLL
             for (int c = 0; c < 7; c++)
               if (c == role && hmap[i] >= 0 && hmap[c] >= 0) { row = S_H + hrow[hmap[i]][hmap[c]]; sgn = 1.0; }
-          } else if (role == 7) { row = S_RZ + i; sgn = -1.0; }
-          else if (role == 8) { row = S_GT + i; sgn = -1.0; }
+          } else if (MP && role == 7) { if (i == 7) { row = S_SC; sgn = 1.0; } }
+          else if (role == RL) { row = S_RZ + i; sgn = -1.0; }
+          else if (role == RL + 1) { row = S_GT + i; sgn = -1.0; }
           grow[i] = row * LDW;
           gsgn[i] = sgn;
         }
       }
-      const double bsc = role == 7 ? -mu : 0.0;
-      const int rowA = (role < 8 ? S_G + role : role < 12 ? S_E + role - 8 : role == 12 ? S_SC : role == 13 ? S_SC + 1
-                        : role == 14 ? S_SC + 4 : S_SC + 2) * LDW;
-      const int rowB = (role < 7 ? S_C + role : role < 14 ? S_F + role - 7 : role == 14 ? S_SC + 3 : S_SC) * LDW;
-      const int rowK = (role < 7 ? role : role < 10 ? role : 10) * LDW;      // out rows 0-6 kap, 7-9 k0, 10 dummy
-      const bool colr = role < 7;
-      const int drow = role == 7 ? 0 : role == 8 ? 1 : 2;                   // what a lane subtracts after the pivot: P c, P rc or nothing
-      double a[7];
+      const double bsc = role == RL ? -mu : 0.0;
+      const int rowA = (role < 8 ? S_G + role : role < 12 ? S_E + role - 8
+                        : MP ? (role == 12 ? S_SC + 1 : role == 13 ? S_SC + 2 : S_SC)
+                        : (role == 12 ? S_SC : role == 13 ? S_SC + 1 : role == 14 ? S_SC + 4 : S_SC + 2)) * LDW;
+      const int rowB = (role < 7 ? S_C + role
+                        : MP ? (role < 13 ? S_F + role - 7 : role == 15 ? S_C + 7 : S_SC)
+                        : (role < 14 ? S_F + role - 7 : role == 14 ? S_SC + 3 : S_SC)) * LDW;
+      const int rowK = (role < NS + 3 ? role : NS + 3) * LDW;      // out rows 0 .. NS-1 kap, NS .. NS+2 k0, NS+3 dummy / pivot
+      const bool colr = role < NS;
+      const int drow = role == RL ? 0 : role == RL + 1 ? 1 : 2;           // what a lane subtracts after the pivot: P c, P rc or nothing
+      double a[NS];
       ASC_UNROLL
-      for (int i = 0; i < 7; i++) a[i] = 0.0;
+      for (int i = 0; i < NS; i++) a[i] = 0.0;
       double U = 0.0, V = 0.0, k10 = 0.0, k11 = 0.0, k12 = 0.0, k20 = 0.0, k22 = 0.0;
       int bad = 0;
       double zK[7];
@@ -664,7 +765,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
           double v = 0.0;
           ASC_UNROLL
           for (int c = 0; c < 7; c++) v = role == c ? Qt[sid(i, c)] : v;
-          if (i < 4) { v = role == 7 ? -r0[i] : v; v = role == 9 ? -tm.e3g[i] : v; }
+          if (i < 4) { v = role == RL ? -r0[i] : v; v = role == RL + 2 ? -tm.e3g[i] : v; }
           a[i] = v;
         }
       }
@@ -674,7 +775,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
           const int k = c * CH + role;
           if (k < K && act) {
             NodeIn n;
-            load_node(it, Kp, K, k, n);
+            load_node<MP>(it, Kp, K, k, n);
             double G[8], E[4], H[10], F[7], fl[7], lt[7], ax, ay;
             ASC_UNROLL
             for (int i = 0; i < 7; i++) lt[i] = SCHEME == 1 ? n.l[i] + n.ln[i] : n.l[i];
@@ -703,15 +804,27 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             for (int i = 0; i < 10; i++) stage[(S_H + i) * LDW + col] = H[i];
             ASC_UNROLL
             for (int i = 0; i < 7; i++) {
-              stage[(S_F + i) * LDW + col] = hT * F[i];            // (pre-scaled: the sweep uses hT F only)
+              if (!MP || i != IM) stage[(S_F + i) * LDW + col] = hT * F[i];            // (pre-scaled: the sweep uses hT F only)
               stage[(S_C + i) * LDW + col] = (FORM == 1 && i == IA) ? n.z[IA] - ha * (n.u + 1.0) : n.z[i] - n.zp[i] - dt * F[i];
               stage[(S_RZ + i) * LDW + col] = (FORM == 1 && i == IA) ? n.l[i] - cs * fl[i] : n.l[i] - cs * fl[i] - n.ln[i];
               stage[(S_GT + i) * LDW + col] = -hTc * fl[i];
             }
             const double scr[5] = {n.zb[4] * id[4] + n.zb[5] * id[5], FORM == 1 ? -ha * n.l[IA] : -be * n.l[IW], id[1] - id[0], id[3] - id[2],
                                    id[5] - id[4]};
-            ASC_UNROLL
-            for (int i = 0; i < 5; i++) stage[(S_SC + i) * LDW + col] = scr[i];
+            if constexpr (MP) {      // row 7 of the stage: the movement equation, the control's stationarity row, the reduced slack pair
+              const MovePivot mvp = move_pivot(n.pp, n.pn, n.zpp, n.zpn, n.lu, dcw, mu, dw);
+              stage[(S_C + 7) * LDW + col] = n.u - n.up - n.pp + n.pn;
+              stage[(S_RZ + 7) * LDW + col] = (scr[1] + (n.lu - n.lun)) + mu * scr[4];
+              stage[(S_GT + 7) * LDW + col] = -hT * d.alpha * n.l[IW];
+              stage[S_SC * LDW + col] = scr[0];
+              stage[(S_SC + 1) * LDW + col] = mvp.Rd;
+              stage[(S_SC + 2) * LDW + col] = mvp.gdl;
+              stage[(S_RZ + IA) * LDW + col] += mu * scr[2];       // (the barrier gradients folded into the residual rows)
+              stage[(S_RZ + IM) * LDW + col] += mu * scr[3];
+            } else {
+              ASC_UNROLL
+              for (int i = 0; i < 5; i++) stage[(S_SC + i) * LDW + col] = scr[i];
+            }
           }
         }
         wsync();
@@ -722,19 +835,19 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             const int k = c * CH + jj;
             if (k >= K) continue;
             const int cj = grp * 16 + jj;
-            double gq[7];
+            double gq[NS];
             ASC_UNROLL
-            for (int i = 0; i < 7; i++) gq[i] = stage[grow[i] + cj];
+            for (int i = 0; i < NS; i++) gq[i] = stage[grow[i] + cj];
             const double gA = stage[rowA + cj], gB = stage[rowB + cj];
             const double G[8] = {bcast16<0>(gA), bcast16<1>(gA), bcast16<2>(gA), bcast16<3>(gA),
                                  bcast16<4>(gA), bcast16<5>(gA), bcast16<6>(gA), bcast16<7>(gA)};
             const double E[4] = {bcast16<8>(gA), bcast16<9>(gA), bcast16<10>(gA), bcast16<11>(gA)};
-            const double R0 = bcast16<12>(gA), ru0 = bcast16<13>(gA), bur = bcast16<14>(gA);
-            const double bza = bcast16<15>(gA), bzm = bcast16<14>(gB);
-            const double cc[7] = {bcast16<0>(gB), bcast16<1>(gB), bcast16<2>(gB), bcast16<3>(gB),
-                                  bcast16<4>(gB), bcast16<5>(gB), bcast16<6>(gB)};
+            const double R0 = bcast16<12>(gA), ru0 = bcast16<13>(gA), bur = bcast16<14>(gA);      // (MP: R0, ru0 = curvature and gradient of the reduced slack pair;
+            const double bza = bcast16<15>(gA), bzm = bcast16<14>(gB);                            //  bur, bza, bzm are not used)
+            const double cc[8] = {bcast16<0>(gB), bcast16<1>(gB), bcast16<2>(gB), bcast16<3>(gB),
+                                  bcast16<4>(gB), bcast16<5>(gB), bcast16<6>(gB), MP ? bcast16<15>(gB) : 0.0};
             const double rc1[7] = {bcast16<7>(gB), bcast16<8>(gB), bcast16<9>(gB), bcast16<10>(gB), bcast16<11>(gB),
-                                   bcast16<12>(gB), bcast16<13>(gB)};
+                                   bcast16<12>(gB), MP ? hT * d.mrate : bcast16<13>(gB)};
             if (FORM == 1 && k < K - 1) {     // step k+1 does not see angle_k: drop its row and column
               a[IA] = 0.0;
               if (role == IA) {
@@ -744,69 +857,91 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             }
             if (SCHEME == 1 && k < K - 1) {   // pull the value function of step k+1 back through Abar = I + cs F_z(z_k): Abar' on every
               double t[7];                    // column and right-hand side, transpose, Abar' on the columns again
-              fzt_lambda(G, a, t);
+              fzt_lambda(G, a, t);            // (MP: the control passes through a step unchanged)
               ASC_UNROLL
               for (int i = 0; i < 7; i++) a[i] += cs * t[i];
               if (colr) {
                 ASC_UNROLL
-                for (int i = 0; i < 7; i++) lds_t[grp][role][i] = a[i];
+                for (int i = 0; i < NS; i++) lds_t[grp][role][i] = a[i];
                 wsync();
-                double r[7];
+                double r[NS];
                 ASC_UNROLL
-                for (int l2 = 0; l2 < 7; l2++) r[l2] = lds_t[grp][l2][role];
+                for (int l2 = 0; l2 < NS; l2++) r[l2] = lds_t[grp][l2][role];
                 fzt_lambda(G, r, t);
                 ASC_UNROLL
                 for (int i = 0; i < 7; i++) a[i] = r[i] + cs * t[i];
+                if constexpr (MP) a[7] = r[7];
               }
               wsync();                        // lds_t is written again below
             }
             ASC_UNROLL
-            for (int i = 0; i < 7; i++) a[i] += gsgn[i] * gq[i];
-            a[IA] += bsc * bza;
-            a[IM] += bsc * bzm;
+            for (int i = 0; i < NS; i++) a[i] += gsgn[i] * gq[i];
+            if constexpr (!MP) {
+              a[IA] += bsc * bza;
+              a[IM] += bsc * bzm;
+            }
             if (dw != 0.0) {
               ASC_UNROLL
-              for (int i = 0; i < 7; i++) a[i] += role == i ? dw : 0.0;
+              for (int i = 0; i < NS; i++) a[i] += role == i ? dw : 0.0;
             }
-            double b[7];
+            // (MP: the extended step Jacobian is [[A, -be e_w], [0, 1]]: its inverse transpose acts as A^-T on the states and
+            //  adds be times the angular-rate component to the control's entry)
+            double b[NS];
             solveAT<FORM>(G, E, cs, a, b);
+            if constexpr (MP) b[7] = a[7] + be * b[IW];
             if (colr) {       // N <- A^-T N A^-1: the columns, transposed through LDS (in order within a wavefront), the columns again
               ASC_UNROLL
-              for (int i = 0; i < 7; i++) lds_t[grp][role][i] = b[i];
+              for (int i = 0; i < NS; i++) lds_t[grp][role][i] = b[i];
               wsync();
-              double t[7];
+              double t[NS];
               ASC_UNROLL
-              for (int l2 = 0; l2 < 7; l2++) t[l2] = lds_t[grp][l2][role];
+              for (int l2 = 0; l2 < NS; l2++) t[l2] = lds_t[grp][l2][role];
               solveAT<FORM>(G, E, cs, t, b);
+              if constexpr (MP) b[7] = t[7] + be * b[IW];
             }
-            double mw[7];
-            ASC_UNROLL
-            for (int i = 0; i < 7; i++) mw[i] = bu * bcast16<IB>(b[i]);
-            const double D = R0 + dw + bu * mw[IB];
+            double mw[NS], D, coef;
+            if constexpr (MP) {       // the stage's control delta enters the movement equation (row 7) with coefficient one
+              ASC_UNROLL
+              for (int i = 0; i < NS; i++) mw[i] = bcast16<7>(b[i]);
+              D = R0 + mw[7];
+            } else {
+              ASC_UNROLL
+              for (int i = 0; i < NS; i++) mw[i] = bu * bcast16<IB>(b[i]);
+              D = R0 + dw + bu * mw[IB];
+            }
             const double iD = rcp(D);
-            const double ru = ru0 + mu * bur, gu = FORM == 1 ? 0.0 : ru0 * ith;
-            const double rsel = role == 7 ? ru : role == 8 ? gu : 0.0;
-            const double coef = (bu * b[IB] - rsel) * iD;
+            if constexpr (MP) {
+              const double rsel = role == RL ? ru0 : 0.0;
+              coef = (b[7] - rsel) * iD;
+            } else {
+              const double ru = ru0 + mu * bur, gu = FORM == 1 ? 0.0 : ru0 * ith;
+              const double rsel = role == 7 ? ru : role == 8 ? gu : 0.0;
+              coef = (bu * b[IB] - rsel) * iD;
+            }
             ASC_UNROLL
-            for (int i = 0; i < 7; i++) a[i] = b[i] - mw[i] * coef;
-            outb[rowK + cj] = role < 10 ? coef : D;          // rows 0-6 kap, 7-9 k0, 10: the pivot (for the flush below)
+            for (int i = 0; i < NS; i++) a[i] = b[i] - mw[i] * coef;
+            outb[rowK + cj] = role < NS + 3 ? coef : D;      // rows 0 .. NS-1 kap, NS .. NS+2 k0, NS+3: the pivot (for the flush below)
             if (colr) {
               double d0 = 0.0, d1 = 0.0;
               ASC_UNROLL
-              for (int i = 0; i < 7; i++) { d0 -= a[i] * cc[i]; d1 += a[i] * rc1[i]; }
+              for (int i = 0; i < NS; i++) {
+                d0 -= a[i] * cc[i];
+                if (i < 7) d1 += a[i] * rc1[i];
+              }
               lds_d[grp][0][role] = d0;
               lds_d[grp][1][role] = d1;
             }
             wsync();
             {     // right-hand-side lanes: a <- a - P c (the column lanes read zeros and keep their a; their U, V are never used)
-              double prc[7];
+              double prc[NS];
               ASC_UNROLL
-              for (int i = 0; i < 7; i++) prc[i] = lds_d[grp][drow][i];
+              for (int i = 0; i < NS; i++) prc[i] = lds_d[grp][drow][i];
               double uu = 0.0, vv = 0.0;
               ASC_UNROLL
-              for (int i = 0; i < 7; i++) {
+              for (int i = 0; i < NS; i++) {
                 const double pj = a[i] - prc[i], sj = a[i] + pj;
-                uu += rc1[i] * sj; vv += cc[i] * sj;
+                if (i < 7) uu += rc1[i] * sj;
+                vv += cc[i] * sj;
                 a[i] = pj;
               }
               U += uu; V += vv;
@@ -821,10 +956,10 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
           if (k < K && act) {
             if (live) {
               ASC_UNROLL
-              for (int i = 0; i < 10; i++) w[(size_t)(R_KA + i) * Kp + k] = outb[i * LDW + col];
+              for (int i = 0; i < NS + 3; i++) w[(size_t)(R_KA + i) * Kp + k] = outb[i * LDW + col];
             }
             // the node's terms of the border's Schur complement and the sign of its pivot (no recurrence: summed here, 16 nodes at a time)
-            const double k00 = outb[7 * LDW + col], k01 = outb[8 * LDW + col], k02 = outb[9 * LDW + col], D = outb[10 * LDW + col];
+            const double k00 = outb[NS * LDW + col], k01 = outb[(NS + 1) * LDW + col], k02 = outb[(NS + 2) * LDW + col], D = outb[(NS + 3) * LDW + col];
             const double Dk1 = D * k01, Dk2 = D * k02;
             k10 += Dk1 * k00; k11 += Dk1 * k01; k12 += Dk1 * k02; k20 += Dk2 * k00; k22 += Dk2 * k02;
             if (!(D > 0.0)) bad = 1;
@@ -834,7 +969,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
         PROF(3);
       }
       // ---- border: the 2x2 Schur complement in (theta, nu3); inertia ---------------------------------------------------------
-      const double U0 = bcast16<7>(U), U1 = bcast16<8>(U), V1 = bcast16<8>(V), U2 = bcast16<9>(U), V2 = bcast16<9>(V);
+      const double U0 = bcast16<RL>(U), U1 = bcast16<RL + 1>(U), V1 = bcast16<RL + 1>(V), U2 = bcast16<RL + 2>(U), V2 = bcast16<RL + 2>(V);
       k10 = gsum16(k10); k11 = gsum16(k11); k12 = gsum16(k12); k20 = gsum16(k20); k22 = gsum16(k22);
       bad = (int)gmax16((double)bad);
       if (act) {
@@ -895,18 +1030,25 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
         // (lanes 0-5: x y xdot ydot angle angledot, lane 6: du) -- 6 broadcasts and 7 multiply-adds on a dependency chain of 4
         // instead of ~90 instructions on a chain of ~25.  The mass component has no feedback (dz_m,k = dz_m,k-1 + x0_m,k): it is a
         // prefix sum over the nodes, done in the node-parallel phase.
-        const int fbase = (role < 7 ? 7 * role : 0) * LDW;              // rows 7i .. 7i+5: M[i][0..5] (lane 6: -ka), row 7i+6: v[i] (du00)
+        // MP: the control is a state -- du_k = du_{k-1} - cu_k + ddelta_k with the stage's control ddelta_k = dd0_k - ka_k . (dx_{k-1} + x0_k)
+        // over the eight states: one more coefficient per row (the previous control step), lane 6 carries du_k; ddelta_k = du_k - du_{k-1} + cu_k
+        // is taken from the result in the node-parallel phase.
+        constexpr int NC = 6 + MP, FS = NC + 1;                         // coefficients per row; rows per lane (coefficients, then v)
+        const int fbase = (role < 7 ? FS * role : 0) * LDW;             // rows FS i .. FS i + NC - 1: M[i][..] (lane 6: -ka), row FS i + NC: v[i] (du00)
         const int fout = (role < 6 ? role : role == 6 ? 7 : 8) * LDW;   // out rows 0-5 dz, 6 dz_m (from the scan), 7 du, 8 dummy
-        double yown = 0.0, carry_m = 0.0;
-        double rmax = 0.0, gsum = 0.0, adu = 1.0;
+        double yown = 0.0, carry_m = 0.0, carry_u = 0.0;
+        double rmax = 0.0, gsum = 0.0, adu = 1.0, gmove = 0.0, clu = 0.0;
         double dzK[7] = {0, 0, 0, 0, 0, 0, 0};
         for (int c = 0; c < nch; c++) {
           const int kn = c * CH + role;
           const bool on = kn < K && act;
           double a_ = 0.5, m_ = 0.5, u_ = 0.0, zb[6] = {1, 1, 1, 1, 1, 1};
-          double G[8], Gp[8], E[4], x0[7], ka[7], du00 = 0.0;        // (Gp: scheme 1 only, the Jacobian block of node k-1)
+          double G[8], Gp[8], E[4], x0[7], ka[NS], du00 = 0.0;       // (Gp: scheme 1 only, the Jacobian block of node k-1)
+          double x0u = 0.0, pp_ = 1.0, pn_ = 1.0, zpp_ = 0.0, zpn_ = 0.0, lu_ = 0.0;      // (MP only)
           ASC_UNROLL
-          for (int i = 0; i < 7; i++) { x0[i] = 0.0; ka[i] = 0.0; }
+          for (int i = 0; i < 7; i++) x0[i] = 0.0;
+          ASC_UNROLL
+          for (int i = 0; i < NS; i++) ka[i] = 0.0;
           if (on) {
             double z[7], zp[7], F[7], ax, ay;
             ASC_UNROLL
@@ -916,7 +1058,11 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             ASC_UNROLL
             for (int b = 0; b < 6; b++) zb[b] = it[(O_ZB + b) * Kp + kn];
             ASC_UNROLL
-            for (int i = 0; i < 7; i++) ka[i] = w[(size_t)(R_KA + i) * Kp + kn];
+            for (int i = 0; i < NS; i++) ka[i] = w[(size_t)(R_KA + i) * Kp + kn];
+            if constexpr (MP) {
+              pp_ = it[O_PP * Kp + kn]; pn_ = it[O_PN * Kp + kn]; zpp_ = it[O_ZP * Kp + kn]; zpn_ = it[O_ZN * Kp + kn]; lu_ = it[O_LU * Kp + kn];
+              x0u = -(u_ - (kn > 0 ? it[O_U * Kp + kn - 1] : 0.0) - pp_ + pn_);
+            }
             du00 = w[(size_t)R_K0 * Kp + kn] + w[(size_t)(R_K0 + 1) * Kp + kn] * dth + w[(size_t)(R_K0 + 2) * Kp + kn] * dnu3;
             accel<1>(d, z[IX], z[IY], z[IA], z[IM], 0.0, 0.0, ax, ay, G, nullptr);
             rhs_f<FORM>(d, z, u_, ax, ay, F);
@@ -933,6 +1079,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
               x0[i] = hT * F[i] * dth - ((FORM == 1 && i == IA) ? z[IA] - ha * (u_ + 1.0) : z[i] - zp[i] - dt * F[i]);
               du00 -= ka[i] * x0[i];
             }
+            if constexpr (MP) du00 -= ka[7] * x0u;
           }
           // dz_m: inclusive prefix sum of x0_m over the nodes of the NLP (16 here, the chunks before in carry_m)
           double incl = x0[IM];
@@ -948,8 +1095,10 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             double rvx[7], rvy[7];
             ainv_vrows<FORM>(G, E, cs, rvx, rvy);
             // row i of M = (row i of A^-1) - be aW[i] ka',  v[i] = (row i of A^-1) . x0 + be aW[i] du00' + A^-1[i][m] dz_m,k-1,  aW = A^-1 e_w
+            // (MP: du_k = (x0u + dd0) - ka . dx_{k-1} + (1 - ka_u) du_{k-1} takes the place of du_k: one more column, be aW[i] (1 - ka_u))
             auto emit = [&](int i, const double *r, double aw) {
               const double bw = bu * aw;
+              if constexpr (MP) stage[(FS * i + 6) * LDW + col] = bw * (1.0 - ka[7]);
               if (SCHEME == 1) {       // dz_k = M Abar_k dz_{k-1} + v: the row times Abar (= row + cs F_z' row), its mass entry folded into v
                 double m7[7], t[7];
                 ASC_UNROLL
@@ -957,20 +1106,20 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
                 fzt_lambda(Gp, m7, t);
                 ASC_UNROLL
                 for (int j = 0; j < 7; j++) m7[j] += cs * t[j];
-                double v = bw * du00 + m7[IM] * dzm_p;
+                double v = bw * (MP ? x0u + du00 : du00) + m7[IM] * dzm_p;
                 ASC_UNROLL
                 for (int j = 0; j < 7; j++) v += r[j] * x0[j];
                 ASC_UNROLL
-                for (int j = 0; j < 6; j++) stage[(7 * i + j) * LDW + col] = m7[j];
-                stage[(7 * i + 6) * LDW + col] = v;
+                for (int j = 0; j < 6; j++) stage[(FS * i + j) * LDW + col] = m7[j];
+                stage[(FS * i + NC) * LDW + col] = v;
                 return;
               }
-              double v = bw * du00p + r[IM] * dzm_p;
+              double v = bw * (MP ? x0u + du00p : du00p) + r[IM] * dzm_p;
               ASC_UNROLL
               for (int j = 0; j < 7; j++) v += r[j] * x0[j];
               ASC_UNROLL
-              for (int j = 0; j < 6; j++) stage[(7 * i + j) * LDW + col] = (FORM == 1 && j == IA) ? 0.0 : r[j] - bw * ka[j];     // (v1: no coupling to angle_{k-1})
-              stage[(7 * i + 6) * LDW + col] = v;
+              for (int j = 0; j < 6; j++) stage[(FS * i + j) * LDW + col] = (FORM == 1 && j == IA) ? 0.0 : r[j] - bw * ka[j];     // (v1: no coupling to angle_{k-1})
+              stage[(FS * i + NC) * LDW + col] = v;
             };
             // (aW above is A^-1 e_b with b the row the control enters: angledot, or the algebraic angle row of the v1 formulation)
             emit(IVX, rvx, rvx[IB]);
@@ -990,7 +1139,24 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
               for (int j = 0; j < 7; j++) r[j] = j == IW ? 1.0 : 0.0;
               emit(IW, r, FORM == 1 ? 0.0 : 1.0);
             }
-            if (SCHEME == 1) {         // du_k = du00 - ka' Abar_k dz_{k-1}
+            if constexpr (MP) {        // row of du_k (lane 6)
+              double kj[7], v0;
+              if (SCHEME == 1) {
+                double t[7];
+                fzt_lambda(Gp, ka, t);
+                ASC_UNROLL
+                for (int j = 0; j < 7; j++) kj[j] = ka[j] + cs * t[j];
+                v0 = du00 - kj[IM] * dzm_p;
+              } else {
+                ASC_UNROLL
+                for (int j = 0; j < 7; j++) kj[j] = ka[j];
+                v0 = du00p;
+              }
+              ASC_UNROLL
+              for (int j = 0; j < 6; j++) stage[(FS * 6 + j) * LDW + col] = -kj[j];
+              stage[(FS * 6 + 6) * LDW + col] = 1.0 - ka[7];
+              stage[(FS * 6 + NC) * LDW + col] = x0u + v0;
+            } else if (SCHEME == 1) {         // du_k = du00 - ka' Abar_k dz_{k-1}
               double t[7];
               fzt_lambda(Gp, ka, t);
               ASC_UNROLL
@@ -1010,11 +1176,16 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             for (int jj = 0; jj < jn; jj++) {
               const int cj = grp * 16 + jj;
               const double *sj = stage + fbase + cj;
-              const double m0 = sj[0], m1 = sj[LDW], m2 = sj[2 * LDW], m3 = sj[3 * LDW], m4 = sj[4 * LDW], m5 = sj[5 * LDW], vv = sj[6 * LDW];
+              const double m0 = sj[0], m1 = sj[LDW], m2 = sj[2 * LDW], m3 = sj[3 * LDW], m4 = sj[4 * LDW], m5 = sj[5 * LDW], vv = sj[NC * LDW];
               const double b0 = bcast16<0>(yown), b1 = bcast16<1>(yown), b2 = bcast16<2>(yown), b3 = bcast16<3>(yown),
                            b4 = bcast16<4>(yown), b5 = bcast16<5>(yown);
               const double e0 = (vv + m0 * b0) + m2 * b2, e1 = m1 * b1 + m3 * b3, e2 = m4 * b4 + m5 * b5;
-              yown = (e0 + e1) + e2;
+              if constexpr (MP) {
+                const double m6 = sj[6 * LDW], b6 = bcast16<6>(yown);
+                yown = ((e0 + e1) + e2) + m6 * b6;
+              } else {
+                yown = (e0 + e1) + e2;
+              }
               outb[fout + cj] = yown;
             }
           }
@@ -1049,11 +1220,34 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
               ASC_UNROLL
               for (int b = 0; b < 6; b++) stp[(O_ZB + b) * Kp + kn] = dzb[b];
             }
+            if constexpr (MP) {
+              // The movement multiplier from the stage control's own stationarity row, d lambda_u = Rd ddelta + gdl, then the slack pair:
+              // the slack with the larger curvature from its own row (well conditioned), the other one from ddelta = dp - dn (its own row
+              // divides a difference of two nearly equal numbers by a curvature that vanishes for an inactive slack)
+              const double du_p = role > 0 ? outb[7 * LDW + col - 1] : carry_u;
+              const double ddel = (du - du_p) - x0u;
+              const MovePivot mvp = move_pivot(pp_, pn_, zpp_, zpn_, lu_, dcw, mu, dw);
+              const double dlu = mvp.Rd * ddel + mvp.gdl;
+              double dpp, dpn;
+              if (mvp.sgp >= mvp.sgn) { dpp = (dlu - mvp.rp) * rcp(mvp.sgp); dpn = dpp - ddel; }
+              else { dpn = (-dlu - mvp.rn) * rcp(mvp.sgn); dpp = ddel + dpn; }
+              const double dzp = mvp.ip * (mu - zpp_ * dpp) - zpp_, dzn_ = mvp.in_ * (mu - zpn_ * dpn) - zpn_;
+              ASC_FTBR(rmax, mvp.ip, dpp); ASC_FTBR(rmax, mvp.in_, dpn);
+              ASC_FTB(adu, zpp_, dzp); ASC_FTB(adu, zpn_, dzn_);
+              gsum -= dpp * mvp.ip + dpn * mvp.in_;
+              gmove += dpp + dpn;
+              clu -= x0u * (lu_ + dlu);           // c_u (lambda_u + d lambda_u) of the merit function's curvature estimate
+              if (live) {
+                stp[O_LU * Kp + kn] = dlu; stp[O_PP * Kp + kn] = dpp; stp[O_PN * Kp + kn] = dpn; stp[O_ZP * Kp + kn] = dzp; stp[O_ZN * Kp + kn] = dzn_;
+              }
+            }
           }
+          if constexpr (MP) carry_u = outb[7 * LDW + grp * 16 + 15];       // the control step of the chunk's last node
           wsync();
           PROF(6);
         }
         rmax = gmax16(rmax); gsum = gsum16(gsum); adu = gmin16(adu);
+        if constexpr (MP) { gmove = gsum16(gmove); clu = gsum16(clu); }
         ASC_UNROLL
         for (int i = 0; i < 7; i++) dzK[i] = gsum16(dzK[i]);          // only the lane of the last node holds non-zeros
         // ---- the scalars of the step and the step lengths: known once the primal step is (the adjoint below only adds the
@@ -1080,7 +1274,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
         ASC_FTB(adu, s.zlt, ds.zlt); ASC_FTB(adu, s.zut, ds.zut);
         ASC_FTB(adu, s.zs1, ds.zs1); ASC_FTB(adu, s.zs2, ds.zs2);
         TrialCtx tc;
-        tc.alpha = apr; tc.adu = adu; tc.mlo = mu * 1e-10; tc.mhi = mu * 1e10; tc.hT = hT; tc.first = false;
+        tc.alpha = apr; tc.adu = adu; tc.mlo = mu * 1e-10; tc.mhi = mu * 1e10; tc.hT = hT; tc.first = false; tc.dcw = dcw;
         tc.stt = trial_scal(d, s, ds, apr, adu, mu, false);
         tc.dt = hT * tc.stt.th; tc.be = tc.dt * d.alpha;
         double *in = w + (size_t)((1 - (int)sc[X_CUR]) * NIT) * Kp;
@@ -1100,12 +1294,18 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
           double ccn[7] = {0, 0, 0, 0, 0, 0, 0};
           NodeIn n, dn;                       // loaded here, used again for the trial point after the sweep of the chunk
           if (kn < K && act) {
-            load_node(it, Kp, K, kn, n);
+            load_node<MP>(it, Kp, K, kn, n);
             ASC_UNROLL
             for (int i = 0; i < 7; i++) { dn.z[i] = stp[(O_Z + i) * Kp + kn]; dn.zp[i] = kn > 0 ? stp[(O_Z + i) * Kp + kn - 1] : 0.0; }
             dn.u = stp[O_U * Kp + kn];
             ASC_UNROLL
             for (int b = 0; b < 6; b++) dn.zb[b] = stp[(O_ZB + b) * Kp + kn];
+            if constexpr (MP) {
+              dn.up = kn > 0 ? stp[O_U * Kp + kn - 1] : 0.0;
+              dn.lu = stp[O_LU * Kp + kn];
+              dn.lun = kn + 1 < K ? stp[O_LU * Kp + kn + 1] : 0.0;
+              dn.pp = stp[O_PP * Kp + kn]; dn.pn = stp[O_PN * Kp + kn]; dn.zpp = stp[O_ZP * Kp + kn]; dn.zpn = stp[O_ZN * Kp + kn];
+            }
             const double *dz = dn.z;
             double G[8], E[4], H[10], F[7], fl[7], lt[7], ax, ay;
             ASC_UNROLL
@@ -1215,17 +1415,18 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
               ASC_UNROLL
               for (int i = 0; i < 7; i++) lds_c[grp][i] = dn.l[i];
             }
-            trial_node<SCHEME, FORM>(d, K, Kp, kn, n, dn, tc, live, in, P);
+            trial_node<SCHEME, FORM, MP>(d, K, Kp, kn, n, dn, tc, live, in, P);
           }
           PROF(0);
         }
-        P.reduce16();
+        P.template reduce16<MP>();
         // ---- scalars of the step, merit bookkeeping -------------------------------------------------------------------------
         ccl = gsum16(ccl);
         if (act) {
           cl += ccl;
           const Terminal &tm = tmK;
-          double gd = mu * gsum;
+          double gd = MP ? mu * gsum + dcw * gmove : mu * gsum;
+          if constexpr (MP) cl += clu;
           gd += ds.th * (1.0 - mu / dl_ + mu / dU) - mu * ds.s1 / s.s1 - mu * ds.s2 / s.s2;
           cl += tm.e3 * (s.nu3 + ds.nu3) + sc[X_CG1] * (s.nu1 + ds.nu1) + sc[X_CG2] * (s.nu2 + ds.nu2);
           const double c1 = sc[X_C1], slog = sc[X_SL];
@@ -1240,10 +1441,10 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             put_scal(sc, X_D, ds);
             sc[X_NUP] = nu_pen;
             sc[X_DM] = gd - nu_pen * c1;
-            sc[X_PHI0] = s.th - mu * slog + nu_pen * c1;
+            sc[X_PHI0] = (MP ? s.th + dcw * sc[X_MV] : s.th) - mu * slog + nu_pen * c1;
             sc[X_ALPHA] = apr; sc[X_ADU] = adu; sc[X_LS] = 0.0;
             sc[X_P + 0] = P.rd; sc[X_P + 1] = P.cinf; sc[X_P + 2] = P.pmin; sc[X_P + 3] = P.pmax; sc[X_P + 4] = P.l1;
-            sc[X_P + 5] = P.zsum; sc[X_P + 6] = P.rth; sc[X_P + 7] = P.c1; sc[X_P + 8] = P.sl;
+            sc[X_P + 5] = P.zsum; sc[X_P + 6] = P.rth; sc[X_P + 7] = P.c1; sc[X_P + 8] = P.sl; sc[X_P + 9] = P.mv;
             sc[X_TEVAL] = 1.0;
             sc[X_STATE] = ST_TRIAL;
           }
@@ -1263,47 +1464,54 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
 
 namespace ascent {
 
-static PGeo geo_of(int K, int form = 0) {
+static PGeo geo_of(int K, int form = 0, int mp = 0) {
   PGeo g;
-  g.K = K; g.nch = (K + CH - 1) / CH; g.Kp = g.nch * CH; g.form = form;
+  g.K = K; g.nch = (K + CH - 1) / CH; g.Kp = g.nch * CH; g.form = form; g.mp = mp ? 1 : 0;
   return g;
 }
 
-size_t persist_ws_bytes(int K, long batch) { return (size_t)batch * geo_of(K).nlp_doubles() * sizeof(double) + 64; }
+// One grid level's workspace, rounded up to a multiple of 256 bytes: the two regions of the nested iteration are laid out
+// back to back with exactly these sizes (persist_region1_offset below is the one place that says where the second one starts).
+size_t persist_ws_bytes(int K, long batch, int mp) {
+  const size_t b = (size_t)batch * geo_of(K, 0, mp).nlp_doubles() * sizeof(double) + 64;
+  return (b + 255) & ~(size_t)255;
+}
+size_t persist_region1_offset(const int *levels, long batch, int mp) { return persist_ws_bytes(levels[0] - 1, batch, mp); }
+size_t persist_level_bytes_used(int K, long batch, int mp) { return (size_t)batch * geo_of(K, 0, mp).nlp_doubles() * sizeof(double); }
+size_t persist_ws_bytes_nested(const int *levels, int nlev, long batch, int mp) {
+  size_t b = persist_region1_offset(levels, batch, mp);
+  if (nlev > 1) b += persist_ws_bytes(levels[1] - 1, batch, mp);
+  return b;
+}
 
 #define PCHK2(call) do { hipError_t e_ = (call); if (e_ != hipSuccess) { snprintf(err, errlen, "%s: %s", #call, hipGetErrorString(e_)); return ASCENT_E_HIP; } } while (0)
 
-int persist_run(const ascent_params *dp, long batch, int K, double *ws, const double *dguess, int warm, int max_iter, double tol,
-                double mu0, double *dtraj, double *dtf, int *dstatus, int *diters, double *dblob, hipStream_t stream, char *err,
-                size_t errlen) {
-  const int levels[1] = {K + 1};
-  return persist_run_nested(dp, batch, 0, 0, levels, 1, ws, dguess, warm, max_iter, tol, tol, mu0, 0.0, 0.0, dtraj, dtf, dstatus, diters, dblob,
-                            stream, err, errlen);
-}
-
-size_t persist_ws_bytes_nested(const int *levels, int nlev, long batch) {
-  size_t b = persist_ws_bytes(levels[0] - 1, batch);
-  if (nlev > 1) b += persist_ws_bytes(levels[1] - 1, batch);
-  return b;
+static void launch_solve(int scheme, int form, int mp, long batch, hipStream_t stream, const ascent_params *dp, const PGeo &g, double *w,
+                         int max_iter, double tol) {
+  const dim3 grid((unsigned)((batch + NPW - 1) / NPW)), block(WAVE);
+  if (mp && scheme == 1) hipLaunchKernelGGL((p_solve<1, 0, 1>), grid, block, 0, stream, dp, batch, g, w, max_iter, tol);
+  else if (mp) hipLaunchKernelGGL((p_solve<0, 0, 1>), grid, block, 0, stream, dp, batch, g, w, max_iter, tol);
+  else if (scheme == 1) hipLaunchKernelGGL((p_solve<1, 0, 0>), grid, block, 0, stream, dp, batch, g, w, max_iter, tol);
+  else if (form == 1) hipLaunchKernelGGL((p_solve<0, 1, 0>), grid, block, 0, stream, dp, batch, g, w, max_iter, tol);
+  else hipLaunchKernelGGL((p_solve<0, 0, 0>), grid, block, 0, stream, dp, batch, g, w, max_iter, tol);
 }
 
 // All grid levels of the nested iteration (levels[0] = the requested grid, finest first; the coarsest is solved first, cold or
 // from the caller's guess): p_init, then per level p_solve and p_transfer to the next finer grid, p_finish at the end.  Two
-// workspace regions alternate between the levels.
-int persist_run_nested(const ascent_params *dp, long batch, int scheme, int form, const int *levels, int nlev, double *ws, const double *dguess, int warm,
+// workspace regions alternate between the levels.  mp: with the l1 move penalty (schemes 0 / 1, formulation 0).
+int persist_run_nested(const ascent_params *dp, long batch, int scheme, int form, int mp, const int *levels, int nlev, double *ws, const double *dguess, int warm,
                        int max_iter, double tol, double tol_coarse, double mu0, double mu_first, double mu_next, double *dtraj,
                        double *dtf, int *dstatus, int *diters, double *dblob, hipStream_t stream, char *err, size_t errlen) {
-  double *region[2] = {ws, (double *)((char *)ws + ((persist_ws_bytes(levels[0] - 1, batch) + 255) & ~(size_t)255))};
-  PGeo g = geo_of(levels[nlev - 1] - 1, form);
+  if (mp && form != 0) { snprintf(err, errlen, "the persistent kernel carries the move penalty for formulation 0 only"); return ASCENT_E_ARG; }
+  double *region[2] = {ws, (double *)((char *)ws + persist_region1_offset(levels, batch, mp))};
+  PGeo g = geo_of(levels[nlev - 1] - 1, form, mp);
   double *w = region[(nlev - 1) & 1];
   hipLaunchKernelGGL(p_init, dim3((unsigned)((g.Kp + WAVE - 1) / WAVE), (unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g, w, dguess,
                      warm, mu0, (const double *)nullptr, (const double *)nullptr);
   for (int l = nlev - 1; l >= 0; l--) {
-    if (scheme == 1) hipLaunchKernelGGL((p_solve<1, 0>), dim3((unsigned)((batch + NPW - 1) / NPW)), dim3(WAVE), 0, stream, dp, batch, g, w, max_iter, l == 0 ? tol : tol_coarse);
-    else if (form == 1) hipLaunchKernelGGL((p_solve<0, 1>), dim3((unsigned)((batch + NPW - 1) / NPW)), dim3(WAVE), 0, stream, dp, batch, g, w, max_iter, l == 0 ? tol : tol_coarse);
-    else hipLaunchKernelGGL((p_solve<0, 0>), dim3((unsigned)((batch + NPW - 1) / NPW)), dim3(WAVE), 0, stream, dp, batch, g, w, max_iter, l == 0 ? tol : tol_coarse);
+    launch_solve(scheme, form, mp, batch, stream, dp, g, w, max_iter, l == 0 ? tol : tol_coarse);
     if (l > 0) {
-      const PGeo gf = geo_of(levels[l - 1] - 1, form);
+      const PGeo gf = geo_of(levels[l - 1] - 1, form, mp);
       double *wf = region[(l - 1) & 1];
       hipLaunchKernelGGL(p_transfer, dim3((unsigned)((gf.Kp + WAVE - 1) / WAVE), (unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g,
                          (const double *)w, gf, wf, l == nlev - 1 ? mu_first : mu_next);
@@ -1317,15 +1525,15 @@ int persist_run_nested(const ascent_params *dp, long batch, int scheme, int form
 }
 
 // One round of p_solve at a caller-supplied iterate (parity surface ascent_kkt_step_path): the iterate as it is, mu and
-// delta_w per problem from the caller; p_probe_out hands back the Newton step.
-int persist_probe(const ascent_params *dp, long batch, int scheme, int form, int K, double *ws, const double *diterate, const double *dmu, const double *ddw,
+// delta_w per problem from the caller; p_probe_out hands back the Newton step.  (mp: the slack pairs, which the blob does
+// not carry, are set around the iterate's own movement as every warm start sets them.)
+int persist_probe(const ascent_params *dp, long batch, int scheme, int form, int mp, int K, double *ws, const double *diterate, const double *dmu, const double *ddw,
                   double *dstep, int *dinertia, hipStream_t stream, char *err, size_t errlen) {
-  const PGeo g = geo_of(K, form);
+  if (mp && form != 0) { snprintf(err, errlen, "the persistent kernel carries the move penalty for formulation 0 only"); return ASCENT_E_ARG; }
+  const PGeo g = geo_of(K, form, mp);
   const dim3 ng((unsigned)((g.Kp + WAVE - 1) / WAVE), (unsigned)batch);
   hipLaunchKernelGGL(p_init, ng, dim3(WAVE), 0, stream, dp, batch, g, ws, diterate, 2, 0.1, dmu, ddw);
-  if (scheme == 1) hipLaunchKernelGGL((p_solve<1, 0>), dim3((unsigned)((batch + NPW - 1) / NPW)), dim3(WAVE), 0, stream, dp, batch, g, ws, 1000, -1.0);
-  else if (form == 1) hipLaunchKernelGGL((p_solve<0, 1>), dim3((unsigned)((batch + NPW - 1) / NPW)), dim3(WAVE), 0, stream, dp, batch, g, ws, 1000, -1.0);
-  else hipLaunchKernelGGL((p_solve<0, 0>), dim3((unsigned)((batch + NPW - 1) / NPW)), dim3(WAVE), 0, stream, dp, batch, g, ws, 1000, -1.0);
+  launch_solve(scheme, form, mp, batch, stream, dp, g, ws, 1000, -1.0);
   hipLaunchKernelGGL(p_probe_out, ng, dim3(WAVE), 0, stream, batch, g, (const double *)ws, dstep, dinertia);
   PCHK2(hipGetLastError());
   return ASCENT_OK;

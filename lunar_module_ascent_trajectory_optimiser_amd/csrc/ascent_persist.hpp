@@ -6,24 +6,23 @@
 
 namespace ascent {
 
-size_t persist_ws_bytes(int K, long batch);
-
-// One grid level, backward Euler, current formulation: three launches (initial point, the whole interior-point loop, results),
-// all asynchronous on `stream`; device pointers; blob / traj layouts of include/ascent.h.
-int persist_run(const ascent_params *dp, long batch, int K, double *ws, const double *dguess, int warm, int max_iter, double tol,
-                double mu0, double *dtraj, double *dtf, int *dstatus, int *diters, double *dblob, hipStream_t stream, char *err,
-                size_t errlen);
+// Workspace of one grid level (a multiple of 256 bytes); mp: with the l1 move penalty (five more rows per node and iterate).
+size_t persist_ws_bytes(int K, long batch, int mp);
 
 // The whole nested iteration inside the kernel's own layout: levels[0] = the requested grid (nodes), finest first; coarse levels
-// are solved to tol_coarse; a level warm-started from the coarsest grid begins at mu_first, later ones at mu_next.
-size_t persist_ws_bytes_nested(const int *levels, int nlev, long batch);
-int persist_run_nested(const ascent_params *dp, long batch, int scheme, int form, const int *levels, int nlev, double *ws, const double *dguess, int warm,
+// are solved to tol_coarse; a level warm-started from the coarsest grid begins at mu_first, later ones at mu_next.  Two regions
+// alternate between the levels: region 0 at the start of the workspace, region 1 at persist_region1_offset; the total is
+// persist_ws_bytes_nested (tests/test_host.py checks that the last NLP of region 1 ends inside it).
+size_t persist_region1_offset(const int *levels, long batch, int mp);
+size_t persist_ws_bytes_nested(const int *levels, int nlev, long batch, int mp);
+size_t persist_level_bytes_used(int K, long batch, int mp);      // bytes the kernels of one level touch from the start of its region
+int persist_run_nested(const ascent_params *dp, long batch, int scheme, int form, int mp, const int *levels, int nlev, double *ws, const double *dguess, int warm,
                        int max_iter, double tol, double tol_coarse, double mu0, double mu_first, double mu_next, double *dtraj,
                        double *dtf, int *dstatus, int *diters, double *dblob, hipStream_t stream, char *err, size_t errlen);
 
 // One interior-point round of the same kernel at a caller-supplied iterate, mu and delta_w (parity surface): the Newton step in
 // the blob layout, inertia[p] = 1 where the factorisation was refused.
-int persist_probe(const ascent_params *dp, long batch, int scheme, int form, int K, double *ws, const double *diterate, const double *dmu, const double *ddw,
+int persist_probe(const ascent_params *dp, long batch, int scheme, int form, int mp, int K, double *ws, const double *diterate, const double *dmu, const double *ddw,
                   double *dstep, int *dinertia, hipStream_t stream, char *err, size_t errlen);
 
 }  // namespace ascent

@@ -924,8 +924,10 @@ __global__ __launch_bounds__(WAVE) void k_terminal_params(const ascent_params *i
 }
 
 bool use_dense_path(const ascent_opts *o, int64_t batch) {
-  if (o->scheme == 2 || o->solver_path == ASCENT_PATH_DENSE || o->move_penalty) return true;
+  if (o->scheme == 2 || o->solver_path == ASCENT_PATH_DENSE) return true;
   const char *e = getenv("ASCENT_PIPELINE");
+  // (the move penalty exists in the persistent kernel and in the dense-block path: an override that names any other family means the dense one)
+  if (o->move_penalty && ((e && strcmp(e, "persist")) || getenv("ASCENT_FACTOR"))) return true;
   if (e) return !strcmp(e, "dense") && o->formulation == 0;
   // A handful of NLPs cannot fill the hand-tuned kernels (one wavefront per four NLPs, serial over the nodes: 2.8 ms at
   // N=200, 7.3 ms at N=600, 25-31 ms at N=2000 for up to 8 NLPs); the dense-block path with its Newton systems solved by
@@ -1065,7 +1067,8 @@ int check_common(const ascent_params *p, int64_t batch, const ascent_opts *o, in
   if (o->scheme < 0 || o->scheme > 2) { snprintf(g_err, sizeof g_err, "scheme %d not supported (0 = backward Euler, the reference's NODES=2; 1 = trapezoid; 2 = Hermite-Simpson)", o->scheme); return ASCENT_E_ARG; }
   if (o->terminal != 0 && o->terminal != 1) { snprintf(g_err, sizeof g_err, "terminal %d not supported (0 = reference, 1 = ellipse proper)", o->terminal); return ASCENT_E_ARG; }
   if (o->solver_path != ASCENT_PATH_AUTO && o->solver_path != ASCENT_PATH_DENSE) { snprintf(g_err, sizeof g_err, "solver_path must be 0 (automatic) or ASCENT_PATH_DENSE"); return ASCENT_E_ARG; }
-  if ((o->scheme == 2 || o->solver_path == ASCENT_PATH_DENSE || o->move_penalty) && o->formulation != 0) { snprintf(g_err, sizeof g_err, "the dense-block path (scheme 2 / ASCENT_PATH_DENSE / move_penalty) has formulation 0 only"); return ASCENT_E_ARG; }
+  if ((o->scheme == 2 || o->solver_path == ASCENT_PATH_DENSE) && o->formulation != 0) { snprintf(g_err, sizeof g_err, "the dense-block path (scheme 2 / ASCENT_PATH_DENSE) has formulation 0 only"); return ASCENT_E_ARG; }
+  if (o->move_penalty && o->formulation != 0) { snprintf(g_err, sizeof g_err, "move_penalty = 1 is carried for formulation 0 only"); return ASCENT_E_ARG; }
   if (o->move_penalty != 0 && o->move_penalty != 1) { snprintf(g_err, sizeof g_err, "move_penalty must be 0 or 1"); return ASCENT_E_ARG; }
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { snprintf(g_err, sizeof g_err, "no HIP device available"); return ASCENT_E_NODEVICE; }
@@ -1081,6 +1084,25 @@ struct DevBuf {  // device staging buffer for host-pointer calls
 };
 
 }  // namespace
+
+// grid levels of the nested iteration, finest first (levels[0] = n_nodes); one level = a plain solve
+static int nested_levels(const ascent_opts *o, int *levels) {
+  int nlev = 1;
+  levels[0] = o->n_nodes;
+  if (o->warm_start == 0 && o->coarse_nodes != -1) {
+    if (o->coarse_nodes > 0) {
+      levels[nlev++] = o->coarse_nodes;
+    } else {
+      for (int n = o->n_nodes; n >= NESTED_MIN_NODES && nlev < 8;) {
+        const int c = coarse_of(n);
+        if (c >= n) break;
+        levels[nlev++] = c;
+        n = c;
+      }
+    }
+  }
+  return nlev;
+}
 
 extern "C" {
 
@@ -1145,25 +1167,12 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
   const bool pcr = dense && use_pcr_newton(batch, o->move_penalty != 0);
   const bool persist = !dense && use_persist_path(o, batch);
   const bool split = o->scheme == 1 || o->formulation == 1 || use_split_pipeline(batch);
-  // grid levels of the nested iteration, finest first (levels[0] = n_nodes); one level = a plain solve
-  int levels[8], nlev = 1;
-  levels[0] = nt;
-  if (o->warm_start == 0 && o->coarse_nodes != -1) {
-    if (o->coarse_nodes > 0) {
-      levels[nlev++] = o->coarse_nodes;
-    } else {
-      for (int n = nt; n >= NESTED_MIN_NODES && nlev < 8;) {
-        const int c = coarse_of(n);
-        if (c >= n) break;
-        levels[nlev++] = c;
-        n = c;
-      }
-    }
-  }
+  int levels[8];
+  const int nlev = nested_levels(o, levels);
   const int slot = slot_for(device_id, stream);
   DeviceWs &w = g_wss[device_id][slot];
   g_ws_last[device_id] = slot;
-  rc = ensure_ws(w, persist ? persist_ws_bytes_nested(levels, nlev, (long)batch) : dense ? (pcr ? dense_pcr_ws_bytes(K, (long)batch) : dense_ws_bytes(K, (long)batch)) : split ? pipeline_ws_bytes(K, (long)batch) : ws_bytes(K, batch, lpt));
+  rc = ensure_ws(w, persist ? persist_ws_bytes_nested(levels, nlev, (long)batch, (int)o->move_penalty) : dense ? (pcr ? dense_pcr_ws_bytes(K, (long)batch) : dense_ws_bytes(K, (long)batch)) : split ? pipeline_ws_bytes(K, (long)batch) : ws_bytes(K, batch, lpt));
   if (rc) return rc;
   const double mu0 = o->mu_init > 0 ? o->mu_init : (o->warm_start ? 1e-4 : 0.1);
 
@@ -1213,7 +1222,7 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
   double mu_first = NESTED_MU_FIRST, mu_next = nested_mu_next(o->tol);
   if (const char *e = getenv("ASCENT_NESTED_MU")) sscanf(e, "%lf,%lf", &mu_first, &mu_next);      // experiments only ("first,next")
   if (persist) {      // all levels inside the kernel's own layout
-    rc = persist_run_nested(dp, (long)batch, (int)o->scheme, (int)o->formulation, levels, nlev, w.ws, dguess, (int)o->warm_start, (int)o->max_iter, o->tol,
+    rc = persist_run_nested(dp, (long)batch, (int)o->scheme, (int)o->formulation, (int)o->move_penalty, levels, nlev, w.ws, dguess, (int)o->warm_start, (int)o->max_iter, o->tol,
                             fmax(o->tol, NESTED_COARSE_TOL), mu0, mu_first, mu_next, dtraj, dtf, dstatus, diters,
                             dblob, stream, g_err, sizeof g_err);
     if (rc) return rc;
@@ -1278,6 +1287,17 @@ static int resolve_path(int path, const ascent_opts *o, int64_t batch, bool step
   return path;
 }
 
+int ascent_workspace_layout(int64_t batch, const ascent_opts *o, int64_t *out4) {
+  if (!o || !out4 || batch <= 0 || o->n_nodes < 3) return ASCENT_E_ARG;
+  int levels[8];
+  const int nlev = nested_levels(o, levels), mp = (int)o->move_penalty;
+  out4[0] = (int64_t)persist_ws_bytes_nested(levels, nlev, (long)batch, mp);
+  out4[1] = (int64_t)persist_level_bytes_used(levels[0] - 1, (long)batch, mp);
+  out4[2] = nlev > 1 ? (int64_t)persist_region1_offset(levels, (long)batch, mp) : 0;
+  out4[3] = nlev > 1 ? (int64_t)persist_level_bytes_used(levels[1] - 1, (long)batch, mp) : 0;
+  return nlev;
+}
+
 int ascent_default_path(int64_t batch, const ascent_opts *o) {
   if (!o || batch <= 0) return ASCENT_E_ARG;
   return resolve_path(ASCENT_PATH_AUTO, o, batch, true);
@@ -1333,10 +1353,13 @@ int ascent_kkt_step_path(const ascent_params *p, int64_t batch, const ascent_opt
                          int path) {
   int rc = check_common(p, batch, o, device_id);
   if (rc) return rc;
-  if (o->move_penalty) { snprintf(g_err, sizeof g_err, "the parity surfaces take the unpenalised NLP only (move_penalty = 1 is an option of ascent_solve_batch)"); return ASCENT_E_ARG; }
   if (!iterate || !mu || !delta_w || !step || !inertia_out) { snprintf(g_err, sizeof g_err, "null pointer"); return ASCENT_E_ARG; }
   if (path < ASCENT_PATH_AUTO || path > ASCENT_PATH_PERSIST) { snprintf(g_err, sizeof g_err, "unknown path %d", path); return ASCENT_E_ARG; }
   path = resolve_path(path, o, batch, true);
+  if (o->move_penalty && path != ASCENT_PATH_PERSIST && path != ASCENT_PATH_DENSE) { snprintf(g_err, sizeof g_err, "move_penalty = 1 exists in the persistent kernel and in the dense-block path only"); return ASCENT_E_ARG; }
+  if (o->move_penalty)
+    for (int64_t i = 0; i < batch; i++)
+      if (!(p[i].dcost > 0.0)) { snprintf(g_err, sizeof g_err, "move_penalty = 1 needs ascent_params.dcost > 0 (problem %lld has %g)", (long long)i, p[i].dcost); return ASCENT_E_ARG; }
   if (o->scheme == 2 && path != ASCENT_PATH_DENSE) { snprintf(g_err, sizeof g_err, "scheme 2 exists in the dense-block path only"); return ASCENT_E_ARG; }
   if (path == ASCENT_PATH_PERSIST && (o->scheme > 1 || (o->scheme == 1 && o->formulation != 0))) { snprintf(g_err, sizeof g_err, "the persistent kernel has schemes 0 and 1 (formulation 1 with scheme 0 only)"); return ASCENT_E_ARG; }
   if (path == ASCENT_PATH_DENSE && o->formulation != 0) { snprintf(g_err, sizeof g_err, "the dense-block path has formulation 0 only"); return ASCENT_E_ARG; }
@@ -1346,9 +1369,9 @@ int ascent_kkt_step_path(const ascent_params *p, int64_t batch, const ascent_opt
   const int K = o->n_nodes - 1;
   const size_t rows = 21 * (size_t)K + NSC;
   const int lpt = lanes_per_tile(batch);
-  const bool pcr_probe = path == ASCENT_PATH_DENSE && use_pcr_newton(batch);
+  const bool pcr_probe = path == ASCENT_PATH_DENSE && use_pcr_newton(batch, o->move_penalty != 0);
   rc = ensure_ws(g_ws_slot0(device_id), path == ASCENT_PATH_DENSE ? (pcr_probe ? dense_pcr_ws_bytes(K, (long)batch) : dense_ws_bytes(K, (long)batch))
-                            : path == ASCENT_PATH_PERSIST ? persist_ws_bytes(K, (long)batch) : path == ASCENT_PATH_FUSED ? ws_bytes(K, batch, lpt) : pipeline_ws_bytes(K, (long)batch));
+                            : path == ASCENT_PATH_PERSIST ? persist_ws_bytes(K, (long)batch, (int)o->move_penalty) : path == ASCENT_PATH_FUSED ? ws_bytes(K, batch, lpt) : pipeline_ws_bytes(K, (long)batch));
   if (rc) return rc;
   DevBuf<ascent_params> bp;
   DevBuf<double> bit, bmu, bdw, bst;
@@ -1366,10 +1389,10 @@ int ascent_kkt_step_path(const ascent_params *p, int64_t batch, const ascent_opt
   }
   if (path == ASCENT_PATH_DENSE) {
     rc = dense_probe(bp.d, (long)batch, K, (int)o->scheme, 0, g_ws_slot0(device_id).ws, bit.d, bmu.d, bdw.d, true, bst.d, bin.d, nullptr,
-                     0, g_err, sizeof g_err, pcr_probe ? 1 : 0);
+                     0, g_err, sizeof g_err, pcr_probe ? 1 : 0, (int)o->move_penalty);
     if (rc) return rc;
   } else if (path == ASCENT_PATH_PERSIST) {
-    rc = persist_probe(bp.d, (long)batch, (int)o->scheme, (int)o->formulation, K, g_ws_slot0(device_id).ws, bit.d, bmu.d, bdw.d, bst.d, bin.d, 0, g_err, sizeof g_err);
+    rc = persist_probe(bp.d, (long)batch, (int)o->scheme, (int)o->formulation, (int)o->move_penalty, K, g_ws_slot0(device_id).ws, bit.d, bmu.d, bdw.d, bst.d, bin.d, 0, g_err, sizeof g_err);
     if (rc) return rc;
   } else if (path == ASCENT_PATH_FUSED) {
     hipLaunchKernelGGL(k_kkt_step, dim3((unsigned)((batch + lpt - 1) / lpt)), dim3(WAVE), 0, 0, bp.d, (long)batch, lpt, K,

@@ -119,7 +119,8 @@ def solve_batch(params, nt: int = 200, tol: float = 1e-9, max_iter: int = 300, g
     speed at its periapsis; `BatchResult.coast()` then ends at its apoapsis).
     path: "auto" or "dense" (the dense-block path for any scheme).
     move_penalty: apply the reference's MV DCOST (Launch_Optimiser.py:99): objective tf + dcost * sum |u_k - u_{k-1}| with the
-    `dcost` of each parameter set (dense-block path; default off: `dcost` is then ignored).
+    `dcost` of each parameter set (schemes 0 / 1: inside the persistent kernel, the control as the eighth state of a stage;
+    scheme 2: dense-block path; default off: `dcost` is then ignored).
     formulation: 0 / "current" or 1 / "v1" (the PDF appendix script: the angle is the MV; see include/ascent.h).
     coarse_nodes: nested iteration for cold starts (0 automatic, -1 single grid, > 0 explicit coarse grid);
     `iters` then counts the iterations of all grid levels."""
@@ -163,8 +164,10 @@ def eval_nodes(params, iterate: np.ndarray, nt: int = 200, device: int = 0, path
 
 
 def kkt_step(params, iterate: np.ndarray, mu, delta_w, nt: int = 200, device: int = 0, path="auto", scheme=0,
-             formulation=0, terminal=0):
-    """One Newton step of the barrier problem at `iterate` -> (step blob, inertia flags); `path` as in eval_nodes."""
+             formulation=0, terminal=0, move_penalty: bool = False):
+    """One Newton step of the barrier problem at `iterate` -> (step blob, inertia flags); `path` as in eval_nodes.
+    move_penalty (paths "persist" and "dense"): with the l1 move penalty; the slack pairs, which the blob does not carry, are
+    set around the iterate's own movement (p = max(du, 0) + 1e-4, n = max(-du, 0) + 1e-4, z_p = z_n = dcost, lambda_u = 0)."""
     L = _lib.load()
     P = pack(params)
     B = P.shape[0]
@@ -175,7 +178,7 @@ def kkt_step(params, iterate: np.ndarray, mu, delta_w, nt: int = 200, device: in
     dw = np.ascontiguousarray(np.broadcast_to(np.asarray(delta_w, dtype=np.float64), (B,)))
     step = np.empty_like(it)
     inertia = np.empty(B, dtype=np.int32)
-    o = _opts(nt, 0, 1.0, 0, 0.0, scheme, formulation, terminal=terminal)
+    o = _opts(nt, 0, 1.0, 0, 0.0, scheme, formulation, terminal=terminal, move_penalty=move_penalty)
     _lib.check(L.ascent_kkt_step_path(_ptr(P), B, C.byref(o), _ptr(it), _ptr(mu), _ptr(dw), _ptr(step), _ptr(inertia),
                                       device, _lib.PATHS[path]))
     return step, inertia
@@ -239,12 +242,15 @@ def kkt_solve(diag, lower, upper, rhs, border=None, border_diag=None, algo="pcr"
 def solve_batch_torch(params_t, nt: int = 200, tol: float = 1e-9, max_iter: int = 300, guess_t=None,
                       warm_start: int = 0, mu_init: float = 0.0, want_traj: bool = True, want_blob: bool = False,
                       out: dict | None = None, sync: bool = False, coarse_nodes: int = 0, scheme=0,
-                      formulation=0, move_penalty: bool = False) -> dict:
+                      formulation=0, move_penalty: bool = False, terminal=0, path: str = "auto") -> dict:
     """Device-resident variant: `params_t` is a torch float64 CUDA tensor (batch,16); all outputs are
     torch CUDA tensors (allocated here unless passed in `out`).  Enqueues on torch's current stream
-    and returns without waiting unless sync=True.  torch is only the owner of device memory/streams."""
+    and returns without waiting unless sync=True.  torch is only the owner of device memory/streams.
+    Options as solve_batch (scheme, formulation, terminal, path, move_penalty: the weights params_t[:, 15] must be
+    positive then -- checked here on the device, the library cannot look into device memory from the host)."""
     import torch
     L = _lib.load()
+    _lib.require_single_hip_runtime()
     if not (params_t.is_cuda and params_t.dtype == torch.float64 and params_t.is_contiguous()):
         raise ValueError("params_t must be a contiguous float64 CUDA tensor")
     B = params_t.shape[0]
@@ -260,6 +266,8 @@ def solve_batch_torch(params_t, nt: int = 200, tol: float = 1e-9, max_iter: int 
         return t
     if params_t.dim() != 2 or params_t.shape[1] != 16:
         raise ValueError("params_t must have shape (batch, 16)")
+    if move_penalty and not bool((params_t[:, 15] > 0).all()):
+        raise ValueError("move_penalty needs dcost > 0 (column 15 of params_t) for every problem")
     if warm_start not in (0, 1, 2) or (warm_start and guess_t is None):
         raise ValueError("warm_start 1/2 needs guess_t")
     if guess_t is not None and not (guess_t.device == dev and guess_t.dtype == torch.float64 and guess_t.is_contiguous()
@@ -270,7 +278,7 @@ def solve_batch_torch(params_t, nt: int = 200, tol: float = 1e-9, max_iter: int 
     iters = buf("iters", (B,), torch.int32)
     traj = buf("traj", (10, nt, B), torch.float64) if want_traj else None
     blob = buf("blob", (rows, B), torch.float64) if want_blob else None
-    o = _opts(nt, max_iter, tol, warm_start, mu_init, scheme, formulation, coarse_nodes, move_penalty=move_penalty)
+    o = _opts(nt, max_iter, tol, warm_start, mu_init, scheme, formulation, coarse_nodes, terminal, path, move_penalty)
     stream = torch.cuda.current_stream(dev).cuda_stream
     _lib.check(L.ascent_solve_batch(params_t.data_ptr(), B, C.byref(o),
                                     guess_t.data_ptr() if guess_t is not None else None,

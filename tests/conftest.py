@@ -49,18 +49,20 @@ def random_interior_blob(nt, seed, p16, coracle):
     return blob
 
 
-def generic_lu_newton_step(P, nt, blob, mu, dw, scheme=0):
+def generic_lu_newton_step(P, nt, blob, mu, dw, scheme=0, move_penalty=False):
     """The Newton step of the barrier problem at a primal-dual iterate (blob layout of include/ascent.h) from a generic
     sparse LU of the full KKT matrix assembled by the numpy oracle -- no stage structure, no Riccati recursion, no
     border elimination: the independent anchor for every stage-structured implementation (C oracle, HIP paths).
-    Returns the step in the same blob layout (current formulation)."""
+    Returns the step in the same blob layout (current formulation).  move_penalty: the NLP with the l1 move penalty
+    (P.dcost; slack pairs and movement equations as explicit unknowns and rows of the generalised oracle -- nothing reduced);
+    the slack pairs, which the blob does not carry, are set by the warm-start rule of include/ascent.h / c_oracle.newton_step."""
     import scipy.sparse as sp
     import scipy.sparse.linalg as spla
     from oracle.ascent_numpy import AscentNLP
     K = nt - 1
-    if scheme == 2:      # Hermite-Simpson: the generalised oracle (sympy-generated derivatives), same variable layout
+    if scheme == 2 or move_penalty:      # the generalised oracle (sympy-generated derivatives), same variable layout
         from oracle.ascent_general import GeneralNLP
-        nlp = GeneralNLP(P, ((K, "burn"),), 2)
+        nlp = GeneralNLP(P, ((K, "burn"),), scheme, dcost=P.dcost if move_penalty else 0.0)
     else:
         nlp = AscentNLP(P, nt, 0, scheme=scheme)
     v = np.zeros(nlp.n); lam = np.zeros(nlp.m); zL = np.zeros(nlp.n); zU = np.zeros(nlp.n)
@@ -73,6 +75,11 @@ def generic_lu_newton_step(P, nt, blob, mu, dw, scheme=0):
     v[nlp.itf], zL[nlp.itf], zU[nlp.itf] = sc[0], sc[1], sc[2]
     v[nlp.is1], v[nlp.is2], zL[nlp.is1], zL[nlp.is2] = sc[3], sc[4], sc[5], sc[6]
     lam[-3], lam[-2], lam[-1] = sc[7], sc[8], sc[9]
+    if move_penalty:
+        du_ = np.diff(np.concatenate([[0.0], blob[7 * K:8 * K]]))
+        v[nlp.ip], v[nlp.in_] = np.maximum(du_, 0.0) + 1e-4, np.maximum(-du_, 0.0) + 1e-4
+        zL[nlp.ip] = zL[nlp.in_] = P.dcost
+        lam[nlp.rmove] = 0.0
     hasL, hasU = np.isfinite(nlp.lb), np.isfinite(nlp.ub)
     dL = np.where(hasL, v - nlp.lb, 1.0); dU = np.where(hasU, nlp.ub - v, 1.0)
     c = nlp.constraints(v)

@@ -290,8 +290,9 @@ def test_pcr_newton_variant_and_small_batch_dispatch(coracle, monkeypatch):
 
 
 def test_move_penalty_matches_independent_fixtures():
-    """a12, Launch_Optimiser.py:99: the MV's DCOST as an l1 term (ascent_opts.move_penalty = 1; dense-block path, the control as the
-    eighth state of a stage, the slack pair reduced to one pivot) against tests/golden/dcost_fixtures.json -- the numpy
+    """a12, Launch_Optimiser.py:99: the MV's DCOST as an l1 term (ascent_opts.move_penalty = 1: the control as the eighth state of
+    a stage, the slack pair reduced to one pivot -- through the default dispatch, i.e. the persistent kernel for schemes 0 / 1
+    and the dense-block path for scheme 2, and through the dense-block path for every scheme) against tests/golden/dcost_fixtures.json -- the numpy
     generic-LU oracle's solutions with and without the penalty (scripts/make_dcost_fixtures.py): backward Euler, trapezoid and
     Hermite-Simpson, dcost 1e-5 (the reference's) to 1e-3, nominal and off-nominal parameters, nested grids.  t_f to 2e-8
     (fixtures at tol 1e-10, GPU at 1e-9), the control's total variation to 0.2 %, the control itself to 5e-3 of its [-1, 1]
@@ -301,8 +302,8 @@ def test_move_penalty_matches_independent_fixtures():
     assert len(fx["cases"]) >= 6
     for c in fx["cases"]:
         P = A.AscentParams(**c["params"])
-        for on in (False, True):
-            r = A.solve_batch(P, c["nt"], tol=1e-9, scheme=c["scheme"], max_iter=500, move_penalty=on)
+        for on, path in ((False, "auto"), (True, "auto"), (True, "dense")):
+            r = A.solve_batch(P, c["nt"], tol=1e-9, scheme=c["scheme"], max_iter=500, move_penalty=on, path=path)
             ref = c["on" if on else "off"]
             u = r.traj[8, 1:, 0]
             tv = np.abs(np.diff(np.concatenate([[0.0], u]))).sum()
@@ -318,14 +319,15 @@ def test_move_penalty_matches_independent_fixtures():
 
 def test_move_penalty_batch_and_dispatch():
     """A batch through move_penalty = 1: every NLP converges, the penalty raises t_f and lowers the control's total variation on
-    every problem; the default dispatch reports the dense-block path for it; bad values are refused."""
+    every problem; the default dispatch reports the persistent kernel for it (schemes 0 / 1); bad values are refused."""
     S = A.sweep_isp_drymass(3, 3)
     assert np.all(S[:, 15] == 0.0)                      # (this package's sweeps carry no weight of their own)
     from lunar_module_ascent_trajectory_optimiser_amd._lib import AscentLibraryError
     with pytest.raises(AscentLibraryError, match="dcost > 0"):
         A.solve_batch(S, 100, tol=1e-9, move_penalty=True)
     S[:, 15] = 1e-5                                     # the reference's DCOST
-    assert A.default_path(9, 100, move_penalty=True) == "dense" and A.default_path(4096, 200, move_penalty=True) == "dense"
+    assert A.default_path(9, 100, move_penalty=True) == "persist" and A.default_path(4096, 200, move_penalty=True) == "persist"
+    assert A.default_path(9, 100, scheme=2, move_penalty=True) == "dense"
     off = A.solve_batch(S, 100, tol=1e-9)
     on = A.solve_batch(S, 100, tol=1e-9, move_penalty=True, max_iter=500)
     assert np.all(off.status == 0) and np.all(on.status == 0)
@@ -340,7 +342,7 @@ def test_move_penalty_batch_and_dispatch():
     for env in ("pcr", "riccati"):
         os.environ["ASCENT_DENSE_NEWTON"] = env
         try:
-            rr = A.solve_batch(S, 100, tol=1e-9, move_penalty=True, max_iter=500)
+            rr = A.solve_batch(S, 100, tol=1e-9, move_penalty=True, max_iter=500, path="dense")
         finally:
             del os.environ["ASCENT_DENSE_NEWTON"]
         assert np.all(rr.status == 0) and np.abs(rr.tf - on.tf).max() <= 2e-9 and np.abs(rr.iters.astype(int) - on.iters).max() <= 4

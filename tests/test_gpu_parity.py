@@ -133,6 +133,67 @@ def test_kkt_step_matches_oracle(coracle, path, scheme, form):
     assert n_ok >= 3
 
 
+@pytest.mark.parametrize("path,scheme", [("persist", 0), ("persist", 1), ("dense", 0), ("dense", 1)])
+def test_kkt_step_with_move_penalty_matches_oracle_and_generic_lu(coracle, path, scheme):
+    """a12 (Launch_Optimiser.py:99) at step level: one Newton step of the barrier problem WITH the l1 move penalty through one
+    round of p_solve<.,0,1> (the control as the eighth state of the 16-lane sweeps, the slack pair reduced to one pivot) and
+    through the dense-block path, against the C restatement (1e-9) and against a generic sparse LU of the full KKT matrix in
+    which the slack pairs and the movement equations are explicit unknowns and rows (nothing reduced, 1e-8)."""
+    from conftest import generic_lu_newton_step, params_of_row
+    nt = 60
+    Kk = nt - 1
+    S = A.sweep_isp_drymass(2, 3)
+    S[:, 15] = [1e-5, 1e-5, 1e-3, 1e-4, 1e-5, 1e-2]
+    blobs = _interior_blobs(coracle, S, nt, scheme, 0)
+    mu = np.array([0.1, 0.02, 1e-3, 0.05, 1e-6, 0.2]); dw = np.array([0.0, 0.0, 1e-2, 1.0, 0.0, 1e-4])
+    step, inertia = A.kkt_step(S, blobs, mu, dw, nt, path=path, scheme=scheme, move_penalty=True)
+    n_ok = 0
+    for b in range(len(S)):
+        blob = np.ascontiguousarray(blobs[:, b])
+        rc, ref = coracle.newton_step(S[b], nt, blob, mu[b], dw[b], scheme=scheme, move_penalty=True)
+        coracle.set_scheme(0)
+        assert rc == inertia[b]
+        if rc:
+            continue
+        n_ok += 1
+        assert np.abs(step[:, b] - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+        lu, _, _, _ = generic_lu_newton_step(params_of_row(S[b]), nt, blob, mu[b], dw[b], scheme, move_penalty=True)
+        for lo, hi in ((0, 8 * Kk), (8 * Kk, 15 * Kk), (15 * Kk, 21 * Kk), (21 * Kk, 21 * Kk + 10)):
+            assert np.abs(step[lo:hi, b] - lu[lo:hi]).max() <= 1e-8 * max(1.0, np.abs(lu[lo:hi]).max())
+    assert n_ok >= 4
+    # the penalty changes the step: the same call without it differs
+    step0, _ = A.kkt_step(S[:1], blobs[:, :1], mu[:1], dw[:1], nt, path=path, scheme=scheme)
+    assert np.abs(step0[:, 0] - step[:, 0]).max() > 1e-6
+
+
+def test_move_penalty_in_the_persistent_kernel_matches_the_oracle_on_a_sweep(coracle):
+    """a12 at solve level, through the default dispatch (the persistent kernel): a 7 x 6 sweep with the reference's DCOST, both
+    schemes -- every NLP converges, identical iteration counts and t_f to 1e-12 against the C restatement (same algorithm:
+    slack pairs re-centred on every grid level), t_f to 1e-9 against the dense-block path (an independent HIP implementation)."""
+    S = A.sweep_isp_drymass(7, 6)
+    S[:, 15] = 1e-5
+    assert A.default_path(len(S), NT, move_penalty=True) == "persist"
+    for scheme in (0, 1):
+        r = A.solve_batch(S, NT, tol=1e-9, scheme=scheme, move_penalty=True)
+        ref = coracle.solve_batch(S, NT, 300, 1e-9, scheme=scheme, move_penalty=True)
+        coracle.set_scheme(0)
+        assert np.all(r.status == 0) and np.all(ref["status"] == 0)
+        assert np.array_equal(r.iters, ref["iters"])
+        assert np.abs(r.tf - ref["tf"]).max() <= 1e-12
+        assert np.abs(np.moveaxis(r.traj, 2, 0)[:, :8] - ref["traj"][:, :8]).max() < 1e-6
+        dn = A.solve_batch(S[::5], NT, tol=1e-9, scheme=scheme, move_penalty=True, path="dense")
+        assert np.all(dn.status == 0) and np.abs(dn.tf - r.tf[::5]).max() <= 1e-9
+    # ragged batch, dead wavefront groups, an odd grid, an iteration cap, warm start from the penalised solution
+    r5 = A.solve_batch(S[:5], 37, tol=1e-9, move_penalty=True)
+    o5 = coracle.solve_batch(S[:5], 37, 300, 1e-9, move_penalty=True)
+    assert np.all(r5.status == 0) and np.abs(r5.tf - o5["tf"]).max() <= 1e-10 and np.abs(r5.iters.astype(int) - o5["iters"]).max() <= 1
+    rc = A.solve_batch(S[:3], NT, tol=1e-9, move_penalty=True, max_iter=3)
+    assert np.all(rc.status == 1)
+    full = A.solve_batch(S[:6], NT, tol=1e-9, move_penalty=True, want_blob=True)
+    warm = A.solve_batch(S[:6], NT, tol=1e-9, move_penalty=True, guess=full.blob, warm_start=2, mu_init=1e-8)
+    assert np.all(warm.status == 0) and warm.iters.max() <= 12 and np.abs(warm.tf - full.tf).max() <= 1e-8
+
+
 @pytest.mark.parametrize("path", ["fused", "split_lane", "split_wide", "persist"])
 def test_kkt_step_detects_wrong_inertia(coracle, path):
     """A strongly negative curvature (flipped multipliers) must be reported, not solved through."""

@@ -101,8 +101,8 @@ def test_product_does_not_import_oracle():
 def test_default_path_dispatch_rule(monkeypatch):
     """ascent_default_path (include/ascent.h): which kernels a solve of that size runs -- no device work, so checked here.
     Schemes 0 and 1 and the v1 formulation: the persistent kernel, except (formulation 0) a handful of NLPs on a long grid
-    (>= 400 intervals, batch <= min(8, intervals/75)), which take the dense blocks + PCR; scheme 2 and the move penalty
-    (ascent_opts.move_penalty, the reference's DCOST): dense blocks always."""
+    (>= 400 intervals, batch <= min(8, intervals/75)), which take the dense blocks + PCR; scheme 2: dense blocks always.  The
+    move penalty (ascent_opts.move_penalty, the reference's DCOST) rides in the persistent kernel for schemes 0 and 1."""
     import lunar_module_ascent_trajectory_optimiser_amd as A
     for k in ("ASCENT_PIPELINE", "ASCENT_FACTOR", "ASCENT_SMALL_BATCH", "ASCENT_DENSE_NEWTON"):
         monkeypatch.delenv(k, raising=False)
@@ -113,9 +113,50 @@ def test_default_path_dispatch_rule(monkeypatch):
     assert [A.default_path(b, 2000, scheme=1) for b in (8, 9)] == ["dense", "persist"]
     assert [A.default_path(b, 201, formulation=1) for b in (1, 4096, 8192)] == ["persist"] * 3 and A.default_path(4, 2000, formulation=1) == "persist"
     assert A.default_path(4096, 201, scheme=2) == "dense"
-    assert [A.default_path(b, 201, scheme=sc, move_penalty=True) for b in (1, 4096) for sc in (0, 1, 2)] == ["dense"] * 6     # the l1 move penalty
+    assert [A.default_path(b, 201, scheme=sc, move_penalty=True) for b in (1, 4096) for sc in (0, 1, 2)] == ["persist", "persist", "dense"] * 2     # the l1 move penalty
+    assert A.default_path(4096, 201, move_penalty=True) == "persist" and A.default_path(2, 2000, move_penalty=True) == "dense"
     assert A.default_path(1, 2000) == "dense"
     monkeypatch.setenv("ASCENT_SMALL_BATCH", "off")
     assert A.default_path(1, 2000) == "persist"
     monkeypatch.setenv("ASCENT_PIPELINE", "split")
     assert A.default_path(4096, 201) == "split_wide"
+    assert A.default_path(4096, 201, move_penalty=True) == "dense"        # (the split pipeline does not carry the penalty)
+
+
+def test_persistent_workspace_regions_fit_the_allocation(lib):
+    """The two workspace regions of the persistent kernel's nested iteration (levels alternate between them) lie inside the
+    allocation for every batch and grid combination -- the second region starts at a 256-byte boundary behind the first, and
+    the last NLP's record of the largest level living there ends before the allocation does (round 2's layout allocated the
+    unaligned sum and overran by up to 255 bytes).  With and without the move penalty's five extra rows."""
+    out = (C.c_int64 * 4)()
+    for mp in (0, 1):
+        for nt in (40, 60, 200, 201, 600, 2000):
+            for batch in (1, 3, 4, 5, 63, 4096, 32768, 262144):
+                o = _lib.AscentOptsC(n_nodes=nt, scheme=0, max_iter=10, warm_start=0, tol=1e-8, mu_init=0.0, move_penalty=mp)
+                nlev = lib.ascent_workspace_layout(batch, C.byref(o), out)
+                total, used0, off1, used1 = out
+                assert nlev >= 2 and used0 > 0 and used1 > 0
+                assert used0 <= off1 and off1 % 256 == 0 and off1 + used1 <= total, (mp, nt, batch, list(out))
+    o = _lib.AscentOptsC(n_nodes=200, scheme=0, max_iter=10, warm_start=0, tol=1e-8, mu_init=0.0, coarse_nodes=-1)
+    assert lib.ascent_workspace_layout(7, C.byref(o), out) == 1 and out[1] <= out[0] and out[2] == 0
+
+
+def test_one_hip_runtime_per_process(lib):
+    """libascent.so and PyTorch-ROCm each ship / need a libamdhip64; the package maps the one torch will use before it loads
+    libascent.so, so that a later `import torch` does not bring a second runtime into the process (device pointers and
+    streams of one are meaningless to the other) -- VERDICT r02 weak 7."""
+    import subprocess, sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from lunar_module_ascent_trajectory_optimiser_amd import _lib\n"
+            "_lib.load(); a = _lib.hip_runtimes_mapped()\n"
+            "import torch; b = _lib.hip_runtimes_mapped()\n"
+            "_lib.require_single_hip_runtime(); print(len(a), len(b))\n") % ROOT
+    env = {k: v for k, v in os.environ.items() if k != "ASCENT_HIP_RUNTIME"}
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0, out.stderr
+    assert out.stdout.split() == ["1", "1"]
+    env["ASCENT_HIP_RUNTIME"] = "system"      # the explicit opt-out: the device-pointer entry points then refuse
+    code2 = code.replace("_lib.require_single_hip_runtime(); print(len(a), len(b))",
+                         "\ntry:\n    _lib.require_single_hip_runtime(); print('no error')\nexcept _lib.AscentLibraryError as e:\n    print('refused' if 'two HIP runtimes' in str(e) else e)")
+    out = subprocess.run([sys.executable, "-c", code2], capture_output=True, text=True, env=env, timeout=300)
+    assert out.returncode == 0 and out.stdout.strip() == "refused", (out.stdout, out.stderr)

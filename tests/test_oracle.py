@@ -1,6 +1,8 @@
 """CPU tests: the oracle against the reference's golden vectors (tests/golden/golden.json,
 transcribed from /root/reference/Numerical_results.png and PDF p30) and against itself
 (numpy generic sparse-LU interior point vs plain-C stage-structured one)."""
+import os
+
 import numpy as np
 import pytest
 
@@ -308,3 +310,43 @@ def test_c_oracle_matches_independent_sweep_corners(coracle):
         assert np.abs(r["tf"] - np.array([e["tf"] for e in fx[grp]])).max() <= 1e-9
         for fi, key in ((0, "final_x"), (1, "final_y"), (2, "final_xdot"), (3, "final_ydot"), (6, "final_angle"), (9, "final_mass")):
             assert np.abs(r["traj"][:, fi, -1] - np.array([e[key] for e in fx[grp]])).max() <= 1e-6
+
+
+def test_c_oracle_move_penalty_matches_fixtures_and_generic_lu(coracle):
+    """a12 (Launch_Optimiser.py:99) in the plain-C restatement (the control as the eighth state of the Riccati sweeps, the slack
+    pair reduced to one pivot): converged answers against tests/golden/dcost_fixtures.json (the numpy generic-LU oracle's
+    solutions: t_f to 2e-8, the control's total variation to 0.2 %, the control to 5e-3 of its range), and single Newton
+    steps against a generic sparse LU of the full KKT matrix with the slack pairs and movement equations explicit."""
+    import json
+    from conftest import generic_lu_newton_step
+    from oracle.ascent_numpy import Params
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "dcost_fixtures.json")))
+    n = 0
+    for c in fx["cases"]:
+        if c["scheme"] == 2:
+            continue
+        p16 = coracle.pack_params(Params(**c["params"]))
+        for on in (False, True):
+            r = coracle.solve_batch(p16[None], c["nt"], 500, 1e-9, scheme=c["scheme"], move_penalty=on)
+            ref = c["on" if on else "off"]
+            u = r["traj"][0, 8, 1:]
+            tv = np.abs(np.diff(np.concatenate([[0.0], u]))).sum()
+            assert r["status"][0] == 0 and abs(r["tf"][0] - ref["tf"]) <= 2e-8
+            if on:
+                assert abs(tv - ref["total_variation"]) <= 2e-3 * ref["total_variation"] and np.abs(u - np.array(ref["u"])).max() <= 5e-3
+                n += 1
+    coracle.set_scheme(0)
+    assert n >= 5
+    P = Params(dcost=1e-5)
+    p16 = coracle.pack_params(P)
+    for scheme in (0, 1):
+        for seed, (mu, dw) in enumerate([(0.1, 0.0), (1e-3, 1e-2), (1e-6, 0.0)]):
+            nt = 30
+            K = nt - 1
+            blob = coracle.solve_batch(p16[None], nt, 3 + seed, 1e-9, want_blob=True, coarse_nodes=-1, scheme=scheme)["blob"][0].copy()
+            rc, st = coracle.newton_step(p16, nt, blob, mu, dw, scheme=scheme, move_penalty=True)
+            lu, _, _, _ = generic_lu_newton_step(P, nt, blob, mu, dw, scheme, move_penalty=True)
+            assert rc == 0
+            for lo, hi in ((0, 8 * K), (8 * K, 15 * K), (15 * K, 21 * K), (21 * K, 21 * K + 10)):
+                assert np.abs(st[lo:hi] - lu[lo:hi]).max() <= 1e-9 * max(1.0, np.abs(lu[lo:hi]).max())
+    coracle.set_scheme(0)
