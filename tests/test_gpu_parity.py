@@ -134,12 +134,13 @@ def test_kkt_step_matches_oracle(coracle, path, scheme, form):
 
 
 @pytest.mark.parametrize("path,scheme", [("persist", 0), ("persist", 1), ("dense", 0), ("dense", 1)])
-def test_kkt_step_with_move_penalty_matches_oracle_and_generic_lu(coracle, path, scheme):
+def test_kkt_step_with_move_penalty_matches_oracle_and_generic_lu(coracle, monkeypatch, path, scheme):
     """a12 (Launch_Optimiser.py:99) at step level: one Newton step of the barrier problem WITH the l1 move penalty through one
     round of p_solve<.,0,1> (the control as the eighth state of the 16-lane sweeps, the slack pair reduced to one pivot) and
     through the dense-block path, against the C restatement (1e-9) and against a generic sparse LU of the full KKT matrix in
     which the slack pairs and the movement equations are explicit unknowns and rows (nothing reduced, 1e-8)."""
     from conftest import generic_lu_newton_step, params_of_row
+    monkeypatch.setenv("ASCENT_DENSE_NEWTON", "riccati")      # (the dense path's PCR variant exposes no inertia; its Riccati form does)
     nt = 60
     Kk = nt - 1
     S = A.sweep_isp_drymass(2, 3)
@@ -162,8 +163,9 @@ def test_kkt_step_with_move_penalty_matches_oracle_and_generic_lu(coracle, path,
             assert np.abs(step[lo:hi, b] - lu[lo:hi]).max() <= 1e-8 * max(1.0, np.abs(lu[lo:hi]).max())
     assert n_ok >= 4
     # the penalty changes the step: the same call without it differs
-    step0, _ = A.kkt_step(S[:1], blobs[:, :1], mu[:1], dw[:1], nt, path=path, scheme=scheme)
-    assert np.abs(step0[:, 0] - step[:, 0]).max() > 1e-6
+    b = int(np.flatnonzero(inertia == 0)[0])
+    step0, in0 = A.kkt_step(S[b:b + 1], blobs[:, b:b + 1], mu[b:b + 1], dw[b:b + 1], nt, path=path, scheme=scheme)
+    assert in0[0] == 0 and np.abs(step0[:, 0] - step[:, b]).max() > 1e-6
 
 
 def test_move_penalty_in_the_persistent_kernel_matches_the_oracle_on_a_sweep(coracle):
@@ -182,7 +184,7 @@ def test_move_penalty_in_the_persistent_kernel_matches_the_oracle_on_a_sweep(cor
         assert np.abs(r.tf - ref["tf"]).max() <= 1e-12
         assert np.abs(np.moveaxis(r.traj, 2, 0)[:, :8] - ref["traj"][:, :8]).max() < 1e-6
         dn = A.solve_batch(S[::5], NT, tol=1e-9, scheme=scheme, move_penalty=True, path="dense")
-        assert np.all(dn.status == 0) and np.abs(dn.tf - r.tf[::5]).max() <= 1e-9
+        assert np.all(dn.status == 0) and np.abs(dn.tf - r.tf[::5]).max() <= 5e-9     # (<= 32 NLPs: its PCR variant, another regularisation rule)
     # ragged batch, dead wavefront groups, an odd grid, an iteration cap, warm start from the penalised solution
     r5 = A.solve_batch(S[:5], 37, tol=1e-9, move_penalty=True)
     o5 = coracle.solve_batch(S[:5], 37, 300, 1e-9, move_penalty=True)
