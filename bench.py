@@ -4,7 +4,9 @@
 A "step" = one pass of the hot path over one batch per GPU: `batch_per_gpu` independent ascent NLPs
 solved from the built-in cold start to KKT error <= tol, parameters already resident in HBM, results
 left in HBM, then the single result gather (tf, status, iters) to rank 0.
-Workload at N=1: BASELINE.json configs[2] -- the 4096-NLP Isp x dry-mass sweep.
+Workload at N=1: BASELINE.json configs[2] -- the 4096-NLP Isp x dry-mass sweep of the model the reference
+declares, i.e. WITH its MV move penalty angledoubledot.DCOST = 1e-5 (Launch_Optimiser.py:99; --no-dcost times the
+unpenalised NLP as the headline instead; the other variant is always reported beside it as a secondary line).
 With N ranks (weak scaling) every rank solves that same sweep, so the N=1 and N=8 lines time the same per-GPU work;
 --batch-per-gpu 32768 with --gpus 8 is config 4 itself (rank r = its contiguous shard of the 262 144-problem box).
 
@@ -57,15 +59,18 @@ def nested_levels(nt: int) -> list:
     return lv
 
 
-def rank_params(batch: int, rank: int, world: int) -> np.ndarray:
+def rank_params(batch: int, rank: int, world: int, dcost: float = 0.0) -> np.ndarray:
     import lunar_module_ascent_trajectory_optimiser_amd as A
     if batch == 32768 and world == 8:               # exact config-4 shard
         full = A.sweep_config4()
-        return np.ascontiguousarray(full[rank * batch:(rank + 1) * batch])
-    n = int(round(batch ** 0.5))
-    while batch % n:
-        n -= 1
-    return A.sweep_isp_drymass(n, batch // n)       # 4096 -> the 64 x 64 grid of config 3, the same on every rank
+        P = np.ascontiguousarray(full[rank * batch:(rank + 1) * batch])
+    else:
+        n = int(round(batch ** 0.5))
+        while batch % n:
+            n -= 1
+        P = A.sweep_isp_drymass(n, batch // n)      # 4096 -> the 64 x 64 grid of config 3, the same on every rank
+    P[:, 15] = dcost                                # the MV's DCOST (Launch_Optimiser.py:99); used with move_penalty only
+    return P
 
 
 def source_sha16() -> str:
@@ -98,7 +103,7 @@ def usable_cores() -> int:
     return int(os.environ.get("ASCENT_CPU_THREADS", n))
 
 
-def cpu_baseline(params: np.ndarray, nt: int, tol: float, sample: int):
+def cpu_baseline(params: np.ndarray, nt: int, tol: float, sample: int, move_penalty: bool = False):
     """Times the plain-C oracle (oracle/ascent_oracle.c, kind "port") on all host cores."""
     from concurrent.futures import ThreadPoolExecutor
     from oracle import c_oracle
@@ -107,10 +112,10 @@ def cpu_baseline(params: np.ndarray, nt: int, tol: float, sample: int):
     idx = np.linspace(0, len(params) - 1, sample).astype(int)
     S = np.ascontiguousarray(params[idx])
     chunks = np.array_split(np.arange(sample), cores * 4)
-    c_oracle.solve_batch(S[:1], nt, 300, tol)      # load + warm
+    c_oracle.solve_batch(S[:1], nt, 300, tol, move_penalty=move_penalty)      # load + warm
     t0 = time.perf_counter()
     with ThreadPoolExecutor(cores) as ex:           # ctypes releases the GIL during the C call
-        res = list(ex.map(lambda ch: c_oracle.solve_batch(S[ch], nt, 300, tol), [c for c in chunks if len(c)]))
+        res = list(ex.map(lambda ch: c_oracle.solve_batch(S[ch], nt, 300, tol, move_penalty=move_penalty), [c for c in chunks if len(c)]))
     dt = time.perf_counter() - t0
     ok = sum(int((r["status"] == 0).sum()) for r in res)
     return dict(value=ok / dt, unit="NLPs/s", cores=cores, kind="port",
@@ -126,6 +131,8 @@ def main():
     ap.add_argument("--batch-per-gpu", type=int, default=4096)
     ap.add_argument("--tol", type=float, default=1e-9)
     ap.add_argument("--cpu-sample", type=int, default=4096)
+    ap.add_argument("--dcost", type=float, default=1e-5, help="weight of the MV move penalty (the reference's DCOST, Launch_Optimiser.py:99)")
+    ap.add_argument("--no-dcost", action="store_true", help="headline on the unpenalised NLP (round 1/2's workload); the penalised one becomes the secondary line")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-continuation", action="store_true", help="skip the secondary warm-start (continuation) measurement")
     ap.add_argument("--no-pipelined", action="store_true", help="skip the secondary two-stream (overlapped batches) measurement")
@@ -157,13 +164,27 @@ def main():
     cdev = dev if args.backend == "nccl" else torch.device("cpu")      # where collectives run
 
     B = args.batch_per_gpu
-    P = rank_params(B, rank, world)
+    mp = not args.no_dcost and args.dcost > 0.0            # the headline's model: with the reference's move penalty
+    P = rank_params(B, rank, world, args.dcost)
     P_t = torch.from_numpy(P).to(dev)                      # inputs resident in HBM before timing
     out = {}
     gathered = [torch.empty((B, 3), dtype=torch.float64, device=cdev) for _ in range(world)] if (dist and rank == 0) else None
 
-    def step():
-        A.solve_batch_torch(P_t, NT, tol=args.tol, want_traj=True, out=out)
+    # The timed steps are enqueued on a stream of their own: with a caller stream and device pointers the library only enqueues
+    # its launches (include/ascent.h; on the default stream it would wait for every solve), so the launches of step i+1 are
+    # queued while step i runs.  The device time of every step is taken from HIP events recorded on that same stream around
+    # the solve's launches and read after the closing synchronisation.
+    main_stream = torch.cuda.Stream(dev)
+    step_events = []
+
+    def step(timed=False):
+        if timed:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(main_stream)
+        A.solve_batch_torch(P_t, NT, tol=args.tol, want_traj=True, out=out, move_penalty=mp)
+        if timed:
+            e1.record(main_stream)
+            step_events.append((e0, e1))
         if dist:                                           # the job's only collective: result gather
             pack = torch.stack([out["tf"], out["status"].double(), out["iters"].double()], dim=1).to(cdev)
             dist.gather(pack, gathered, dst=0)
@@ -173,22 +194,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize(dev)
 
+    def timed_loop(fn, steps):
+        """`steps` calls of fn enqueued on main_stream between two synchronisations: (wall ms per step, mean device ms per step)"""
+        evs = []
+        torch.cuda.synchronize(dev)
+        t1 = time.perf_counter()
+        with torch.cuda.stream(main_stream):
+            for _ in range(steps):
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                a.record(main_stream); fn(); b.record(main_stream)
+                evs.append((a, b))
+        torch.cuda.synchronize(dev)
+        wall = (time.perf_counter() - t1) / steps * 1e3
+        return wall, float(np.mean([a.elapsed_time(b) for a, b in evs]))
+
     conv_steps = torch.zeros((), dtype=torch.int64, device=dev)   # converged NLPs summed over the timed steps (counted on the device)
-    for _ in range(max(args.warmup, 1) if args.warmup else 0):
-        step()
-        conv_steps += (out["status"] == 0).sum()                  # (also warms up torch's own reduction kernel)
-    if not args.warmup:
-        conv_steps += torch.zeros((), dtype=torch.int64, device=dev)
-    conv_steps.zero_()
+    with torch.cuda.stream(main_stream):
+        for _ in range(max(args.warmup, 1) if args.warmup else 0):
+            step()
+            conv_steps += (out["status"] == 0).sum()                  # (also warms up torch's own reduction kernel)
+        if not args.warmup:
+            conv_steps += torch.zeros((), dtype=torch.int64, device=dev)
+        conv_steps.zero_()
     barrier()
-    kernel_ms = []
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        conv_steps += (out["status"] == 0).sum()
-        kernel_ms.append(A.last_kernel_ms(local))          # HIP events on the launch stream (waits for the kernel)
+    with torch.cuda.stream(main_stream):
+        for _ in range(args.steps):
+            step(timed=True)
+            conv_steps += (out["status"] == 0).sum()
     barrier()
     elapsed = time.perf_counter() - t0
+    kernel_ms = [e0.elapsed_time(e1) for e0, e1 in step_events]       # device time of each timed step's launches (all grid levels)
     if dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -209,7 +245,7 @@ def main():
         lv = nested_levels(NT)
         cum = [iters.astype(np.int64)]
         for n in lv[1:]:
-            sub = A.solve_batch_torch(P_t, n, tol=max(args.tol, 1e-3), want_traj=False, sync=True)
+            sub = A.solve_batch_torch(P_t, n, tol=max(args.tol, 1e-3), want_traj=False, sync=True, move_penalty=mp)
             cum.append(sub["iters"].cpu().numpy().astype(np.int64))
         cum.append(np.zeros_like(cum[0]))
         per_level = [cum[i] - cum[i + 1] for i in range(len(lv))]
@@ -235,7 +271,10 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {
                 "workload": ("BASELINE.json configs[2]: 4096-NLP Isp x dry-mass sweep (64x64, Isp 300-320 s, dry mass 2345-2545 kg)"
-                             if B == 4096 else f"{B}-NLP sweep per GPU") + ", N=200 nodes, backward Euler (reference NODES=2)",
+                             if B == 4096 else f"{B}-NLP sweep per GPU") + ", N=200 nodes, backward Euler (reference NODES=2), "
+                            + (f"DCOST applied (the script's MV move penalty {args.dcost:g}, Launch_Optimiser.py:99, as an l1 term: the model the reference declares)"
+                               if mp else "DCOST not applied (the unpenalised NLP; the script's MV move penalty, Launch_Optimiser.py:99, switched off)"),
+                "move_penalty": bool(mp), "dcost": args.dcost if mp else 0.0,
                 "batch_per_gpu": B, "global_batch": B * world, "n_nodes": NT, "tol": args.tol,
                 "start": f"cold (built-in straight-line guess, mu0=0.1) on a {lv[-1]}-node grid, prolonged grid by grid ({' -> '.join(str(n) for n in lv[::-1])} nodes) "
                          "(nested iteration, part of the solver and of the timed step)",
@@ -246,15 +285,16 @@ def main():
                 "kernel_source_sha16": source_sha16(),
             },
             "roofline": {
-                "bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "bound": "hbm", "binding": "fp64_issue", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
                 "kernel": (("p_solve (persistent kernel: one wavefront owns four NLPs for a whole grid level; one launch per grid level, "
-                            f"{len(lv)} levels) + p_init / p_transfer / p_finish") if A.default_path(B, NT) == "persist" else
-                           "k_solve (fused, one lane per NLP), one launch per grid level" if A.default_path(B, NT) == "fused" else
-                           A.default_path(B, NT)),
+                            f"{len(lv)} levels) + p_init / p_transfer / p_finish") if A.default_path(B, NT, move_penalty=mp) == "persist" else
+                           "k_solve (fused, one lane per NLP), one launch per grid level" if A.default_path(B, NT, move_penalty=mp) == "fused" else
+                           A.default_path(B, NT, move_penalty=mp)),
                 "kernel_ms": k_ms, "algorithmic_bytes_per_launch": b_alg,
                 "fp64_achieved_tflops": f_alg / (k_ms * 1e-3) / 1e12,
                 "fp64_frac": f_alg / (k_ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                "algorithmic_bytes_note": "SURVEY 8d's 21 doubles per node read + written per iteration; the penalised NLP carries 26 (lambda_u and the slack pair with its multipliers), not counted",
                 "note": ("kernel_ms = device time of one whole solve (HIP events around all launches of the step; p_solve is 97 % of it: "
                          "profiles/); achieved = SURVEY 8d algorithmic bytes of the solve (iterations x nodes of every grid level x 2 x 21 "
                          "doubles + i/o) / that time. The kernel is FP64-issue bound, not HBM bound: one wavefront per SIMD issues one "
@@ -264,15 +304,12 @@ def main():
         if world == 1 and not args.no_continuation:
             # Secondary, differently-defined number (never `value`): the same sweep under a continuation policy --
             # every NLP warm-started (primal-dual, mu0 = 1e-6) from the solution of the nominal Apollo-11 problem.
-            nom = A.solve_batch(A.AscentParams(tf_ub=float(P[0, 14])), NT, tol=args.tol, want_blob=True)
+            nom = A.solve_batch(A.AscentParams(tf_ub=float(P[0, 14]), dcost=args.dcost), NT, tol=args.tol, want_blob=True, move_penalty=mp)
             g_t = torch.from_numpy(np.ascontiguousarray(np.repeat(nom.blob, B, axis=1))).to(dev)
             wout = {}
-            A.solve_batch_torch(P_t, NT, tol=args.tol, guess_t=g_t, warm_start=2, mu_init=1e-6, want_traj=True, out=wout, sync=True)
-            t1 = time.perf_counter()
-            for _ in range(args.steps):
-                A.solve_batch_torch(P_t, NT, tol=args.tol, guess_t=g_t, warm_start=2, mu_init=1e-6, want_traj=True, out=wout)
-            torch.cuda.synchronize(dev)
-            wdt = (time.perf_counter() - t1) / args.steps
+            A.solve_batch_torch(P_t, NT, tol=args.tol, guess_t=g_t, warm_start=2, mu_init=1e-6, want_traj=True, out=wout, sync=True, move_penalty=mp)
+            wdt = timed_loop(lambda: A.solve_batch_torch(P_t, NT, tol=args.tol, guess_t=g_t, warm_start=2, mu_init=1e-6, want_traj=True, out=wout,
+                                                         move_penalty=mp), args.steps)[0] * 1e-3
             wit = wout["iters"].cpu().numpy()
             wok = int((wout["status"].cpu().numpy() == 0).sum())
             line["continuation"] = {
@@ -280,6 +317,21 @@ def main():
                 "iterations_min_mean_max": [int(wit.min()), float(wit.mean()), int(wit.max())],
                 "max_abs_tf_diff_vs_cold": float((wout["tf"] - out["tf"]).abs().max().item()),
                 "policy": "primal-dual warm start of every NLP from the nominal Apollo-11 solution, mu0=1e-6; not the headline value",
+            }
+        if world == 1 and args.dcost > 0.0:
+            # Secondary (never `value`): the same steps on the OTHER variant of the model, so that both batch numbers stand side by side
+            oout = {}
+            A.solve_batch_torch(P_t, NT, tol=args.tol, want_traj=True, out=oout, move_penalty=not mp, sync=True)
+            odt, okms = timed_loop(lambda: A.solve_batch_torch(P_t, NT, tol=args.tol, want_traj=True, out=oout, move_penalty=not mp), args.steps)
+            odt *= 1e-3
+            oit = oout["iters"].cpu().numpy()
+            ook = int((oout["status"] == 0).sum().item())
+            line["dcost_applied" if not mp else "dcost_not_applied"] = {
+                "value": ook / odt, "unit": "NLPs/s", "ms_per_step": odt * 1e3, "kernel_ms": okms, "converged": ook, "of": B,
+                "iterations_min_mean_max": [int(oit.min()), float(oit.mean()), int(oit.max())],
+                "tf_shift_mean_s": float(((out["tf"] - oout["tf"]).mean() * P[0, 11]).item()) * (1.0 if mp else -1.0),
+                "what": ("the same sweep WITH the script's MV DCOST as an l1 move penalty" if not mp else
+                         "the same sweep WITHOUT the move penalty (rounds 1 and 2 quoted this variant as the headline)") + "; not the headline value",
             }
         if world == 1 and not args.no_pipelined:
             # Secondary (never `value`): the same K solves enqueued alternately on two streams.  The library keeps a workspace per
@@ -290,12 +342,12 @@ def main():
             pouts = [{}, {}]
             for i in range(4):
                 with torch.cuda.stream(streams[i % 2]):
-                    A.solve_batch_torch(P_t, NT, tol=args.tol, want_traj=True, out=pouts[i % 2])
+                    A.solve_batch_torch(P_t, NT, tol=args.tol, want_traj=True, out=pouts[i % 2], move_penalty=mp)
             torch.cuda.synchronize(dev)
             t1 = time.perf_counter()
             for i in range(args.steps):
                 with torch.cuda.stream(streams[i % 2]):
-                    A.solve_batch_torch(P_t, NT, tol=args.tol, want_traj=True, out=pouts[i % 2])
+                    A.solve_batch_torch(P_t, NT, tol=args.tol, want_traj=True, out=pouts[i % 2], move_penalty=mp)
             torch.cuda.synchronize(dev)
             pdt = (time.perf_counter() - t1) / args.steps
             pok = min(int((po["status"] == 0).sum().item()) for po in pouts)
@@ -340,7 +392,7 @@ def main():
                                         "what": "N=2000 Hermite-Simpson, terminal condition of the (r_peri, r_apo) ellipse, Kepler coast on the device; angular-acceleration bound active"}
             line["other_configs"] = oc
         if world == 1 and not args.no_cpu_baseline:
-            cb, idx, res = cpu_baseline(P, NT, args.tol, min(args.cpu_sample, B))
+            cb, idx, res = cpu_baseline(P, NT, args.tol, min(args.cpu_sample, B), move_penalty=mp)
             tf_cpu = np.concatenate([r["tf"] for r in res])
             # the baseline doubles as a live parity check of the timed run
             order = np.concatenate([c for c in np.array_split(np.arange(len(idx)), cb["cores"] * 4) if len(c)])

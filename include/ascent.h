@@ -170,12 +170,15 @@ int ascent_kkt_step(const ascent_params *p, int64_t batch, const ascent_opts *o,
  *   ASCENT_PATH_FUSED       k_eval_nodes / the passes of k_solve (scheme 0, formulation 0 only)
  *   ASCENT_PATH_SPLIT_LANE  q_trial_eval -> q_decide_factor -> q_forward -> q_local -> q_adjoint
  *   ASCENT_PATH_SPLIT_WIDE  q_trial_eval -> q_factor_wide -> q_forward_wide -> q_local -> q_adjoint_wide
+ *   ASCENT_PATH_PERSIST     p_solve (the default of ascent_solve_batch): see the enum below
+ *   ASCENT_PATH_DENSE       d_eval -> d_newton (ascent_kkt_step_path; with move_penalty = 1 as well, like ASCENT_PATH_PERSIST)
  * The split paths take schemes 0/1 and formulations 0/1.  For scheme 1 (trapezoid) `defects` is the trapezoid
  * defect and the Hessian block of node k is weighted by -(h*T*tf/2)*(lambda_k + lambda_{k+1}). */
 enum ascent_path { ASCENT_PATH_AUTO = 0, ASCENT_PATH_FUSED = 1, ASCENT_PATH_SPLIT_LANE = 2, ASCENT_PATH_SPLIT_WIDE = 3,
                    ASCENT_PATH_DENSE = 4, /* d_eval -> d_newton, one wavefront per NLP on dense 8x8 blocks: schemes 0/1/2 */
-                   ASCENT_PATH_PERSIST = 5 /* one round of p_solve, the persistent kernel (ascent_kkt_step_path only: its node
-                                              rows live in LDS; schemes 0 / 1, formulation 1 with scheme 0) */ };
+                   ASCENT_PATH_PERSIST = 5 /* one round of p_solve, the persistent kernel (schemes 0 / 1, formulation 1 with scheme 0):
+                                              ascent_kkt_step_path returns its Newton step; ascent_eval_nodes_path the node rows it
+                                              stages in LDS for the factorisation sweep, copied out before the sweep would read them */ };
 /* Which kernels ascent_solve_batch runs for a batch of this size with these options (and the environment overrides):
  * an ascent_path value, never ASCENT_PATH_AUTO.  No device work. */
 int ascent_default_path(int64_t batch, const ascent_opts *o);

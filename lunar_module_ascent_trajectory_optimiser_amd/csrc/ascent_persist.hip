@@ -67,7 +67,7 @@ enum {
   X_STATE, X_ITERS, X_STATUS, X_CUR, X_FIRST, X_LS, X_MU, X_NUP, X_DW, X_DWL, X_ALPHA, X_ADU, X_PHI0, X_DM, X_C1, X_SL,
   X_RTH, X_DTH, X_DNU3, X_SIG1, X_SIG2, X_RS1, X_RS2, X_CG1, X_CG2,
   X_ITB,                     // iterations spent on the coarser grids of the nested iteration
-  X_PROBE, X_PDW,            // parity probe: one round at the caller's iterate, mu and delta_w, then stop
+  X_PROBE, X_PDW,            // parity probe: one round at the caller's iterate, mu and delta_w, then stop (1: Newton step; 2: the node rows of the factor phase)
   X_TEVAL,                   // the trial point of the next round has been evaluated already (by the adjoint phase)
   X_P,                       // 10 reduced partials of that trial point: rd cinf pmin pmax l1 zsum rth c1 sl mv
   X_PEND = X_P + 9,
@@ -219,7 +219,7 @@ ASC_DEV void store_start(double *w, int Kp, int k, const double *z, const double
 }
 
 __global__ __launch_bounds__(WAVE) void p_init(const ascent_params *params, long batch, PGeo g, double *ws, const double *guess,
-                                               int warm, double mu_init, const double *probe_mu, const double *probe_dw) {
+                                               int warm, double mu_init, const double *probe_mu, const double *probe_dw, int probe_kind) {
   const long p = blockIdx.y;
   const int k = blockIdx.x * WAVE + threadIdx.x, K = g.K, Kp = g.Kp;
   if (k >= Kp) return;
@@ -258,7 +258,7 @@ __global__ __launch_bounds__(WAVE) void p_init(const ascent_params *params, long
   put_scal(sc, X_S, s);
   sc[X_STATE] = ST_TRIAL; sc[X_FIRST] = 1.0; sc[X_STATUS] = ASCENT_MAX_ITER;
   sc[X_MU] = (asked_warm && !warm) ? 0.1 : mu_init; sc[X_NUP] = 1.0;
-  if (probe) { sc[X_MU] = probe_mu[p]; sc[X_PDW] = probe_dw[p]; sc[X_PROBE] = 1.0; }
+  if (probe) { sc[X_MU] = probe_mu[p]; sc[X_PDW] = probe_dw[p]; sc[X_PROBE] = (double)probe_kind; }
 }
 
 // Nested iteration, from one grid to the next finer one without leaving the kernel's own layout: the converged primal-dual
@@ -400,6 +400,29 @@ __global__ __launch_bounds__(WAVE) void p_probe_out(long batch, PGeo g, const do
   step[(7L * K + k) * batch + p] = ok ? stp[O_U * Kp + k] : 0.0;
   ASC_UNROLL
   for (int b = 0; b < 6; b++) step[(15L * K + 6L * k + b) * batch + p] = ok ? stp[(O_ZB + b) * Kp + k] : 0.0;
+}
+
+// p_probe_rows_out: the node rows one probe round (kind 2) dumped from LDS, in the layout of ascent_eval_nodes: defects
+// [7K][batch], Jacobian blocks [8K][batch], Hessian blocks [10K][batch] -- the bound-barrier curvature that the factor phase
+// folds into the (angle, angle) and (mass, mass) entries is taken out again (as q_probe_out does for the split pipeline)
+__global__ __launch_bounds__(WAVE) void p_probe_rows_out(const ascent_params *params, long batch, PGeo g, const double *ws, double *defects,
+                                                         double *jac, double *hess) {
+  const long p = blockIdx.y;
+  const int k = blockIdx.x * WAVE + threadIdx.x, K = g.K, Kp = g.Kp;
+  if (k >= K) return;
+  const double *w = ws + (size_t)p * g.nlp_doubles();
+  const double *sc = w + (size_t)g.nrows() * Kp, *rows = w + (size_t)g.r_st() * Kp;
+  const double *it = w + (size_t)((int)sc[X_CUR] * g.nit()) * Kp;
+  const Der d = derive(params[p]);
+  const double a_ = it[(O_Z + IA) * Kp + k], m_ = it[(O_Z + IM) * Kp + k];
+  const double siga = it[(O_ZB + 0) * Kp + k] * rcp(a_) + it[(O_ZB + 1) * Kp + k] * rcp(d.aub - a_);
+  const double sigm = it[(O_ZB + 2) * Kp + k] * rcp(m_) + it[(O_ZB + 3) * Kp + k] * rcp(1.0 - m_);
+  ASC_UNROLL
+  for (int i = 0; i < 8; i++) jac[(8L * k + i) * batch + p] = rows[i * Kp + k];
+  ASC_UNROLL
+  for (int i = 0; i < 10; i++) hess[(10L * k + i) * batch + p] = rows[(8 + i) * Kp + k] - (i == 7 ? siga : i == 9 ? sigm : 0.0);
+  ASC_UNROLL
+  for (int i = 0; i < 7; i++) defects[(7L * k + i) * batch + p] = rows[(18 + i) * Kp + k];
 }
 
 // ==============================================================================================================
@@ -769,6 +792,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
           a[i] = v;
         }
       }
+      const bool probe_rows = sc[X_PROBE] == 2.0;      // parity probe of the node evaluation: dump the stage rows, no sweep
       for (int c = nch - 1; c >= 0; c--) {
         // ---- node-parallel: the blocks of the 16 nodes of this chunk -------------------------------------------------
         {
@@ -829,6 +853,19 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
         }
         wsync();
         PROF(1);
+        if (probe_rows) {      // the rows the sweep would gather -- Jacobian block, Hessian block (bound terms included), defects -- as they
+          const int k = c * CH + role;                    // stand in LDS, into the step / gain rows of the workspace (p_probe_rows_out)
+          if (k < K && act && live) {
+            ASC_UNROLL
+            for (int i = 0; i < 8; i++) w[(size_t)(R_ST + i) * Kp + k] = stage[(S_G + i) * LDW + col];
+            ASC_UNROLL
+            for (int i = 0; i < 10; i++) w[(size_t)(R_ST + 8 + i) * Kp + k] = stage[(S_H + i) * LDW + col];
+            ASC_UNROLL
+            for (int i = 0; i < 7; i++) w[(size_t)(R_ST + 18 + i) * Kp + k] = stage[(S_C + i) * LDW + col];
+          }
+          wsync();
+          continue;
+        }
         // ---- serial: the 16 steps of the chunk, backwards; 16 lanes per NLP (the arithmetic of q_factor_wide) -----------
         if (act) {
           for (int jj = CH - 1; jj >= 0; jj--) {
@@ -972,7 +1009,9 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
       const double U0 = bcast16<RL>(U), U1 = bcast16<RL + 1>(U), V1 = bcast16<RL + 1>(V), U2 = bcast16<RL + 2>(U), V2 = bcast16<RL + 2>(V);
       k10 = gsum16(k10); k11 = gsum16(k11); k12 = gsum16(k12); k20 = gsum16(k20); k22 = gsum16(k22);
       bad = (int)gmax16((double)bad);
-      if (act) {
+      if (probe_rows) {
+        if (act && role == 0) sc[X_STATE] = ST_DONE;
+      } else if (act) {
         const double S10 = k10 + 0.5 * (U0 - V1), S11 = k11 + U1, S12 = k12 + 0.5 * U2, S20 = k20 - 0.5 * V2, S22 = k22;
         int ok = !bad;
         double dth = 0.0, dnu3 = 0.0;
@@ -1507,7 +1546,7 @@ int persist_run_nested(const ascent_params *dp, long batch, int scheme, int form
   PGeo g = geo_of(levels[nlev - 1] - 1, form, mp);
   double *w = region[(nlev - 1) & 1];
   hipLaunchKernelGGL(p_init, dim3((unsigned)((g.Kp + WAVE - 1) / WAVE), (unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g, w, dguess,
-                     warm, mu0, (const double *)nullptr, (const double *)nullptr);
+                     warm, mu0, (const double *)nullptr, (const double *)nullptr, 0);
   for (int l = nlev - 1; l >= 0; l--) {
     launch_solve(scheme, form, mp, batch, stream, dp, g, w, max_iter, l == 0 ? tol : tol_coarse);
     if (l > 0) {
@@ -1532,9 +1571,23 @@ int persist_probe(const ascent_params *dp, long batch, int scheme, int form, int
   if (mp && form != 0) { snprintf(err, errlen, "the persistent kernel carries the move penalty for formulation 0 only"); return ASCENT_E_ARG; }
   const PGeo g = geo_of(K, form, mp);
   const dim3 ng((unsigned)((g.Kp + WAVE - 1) / WAVE), (unsigned)batch);
-  hipLaunchKernelGGL(p_init, ng, dim3(WAVE), 0, stream, dp, batch, g, ws, diterate, 2, 0.1, dmu, ddw);
+  hipLaunchKernelGGL(p_init, ng, dim3(WAVE), 0, stream, dp, batch, g, ws, diterate, 2, 0.1, dmu, ddw, 1);
   launch_solve(scheme, form, mp, batch, stream, dp, g, ws, 1000, -1.0);
   hipLaunchKernelGGL(p_probe_out, ng, dim3(WAVE), 0, stream, batch, g, (const double *)ws, dstep, dinertia);
+  PCHK2(hipGetLastError());
+  return ASCENT_OK;
+}
+
+// The node rows of the same kernel (parity surface ascent_eval_nodes_path): one round of p_solve up to the point where the
+// blocks of every chunk stand in LDS; they are copied out instead of being swept.  dzero: a device array of `batch` zeros
+// (mu and delta_w do not enter the rows).
+int persist_probe_rows(const ascent_params *dp, long batch, int scheme, int form, int K, double *ws, const double *diterate, const double *dzero,
+                       double *ddefects, double *djac, double *dhess, hipStream_t stream, char *err, size_t errlen) {
+  const PGeo g = geo_of(K, form, 0);
+  const dim3 ng((unsigned)((g.Kp + WAVE - 1) / WAVE), (unsigned)batch);
+  hipLaunchKernelGGL(p_init, ng, dim3(WAVE), 0, stream, dp, batch, g, ws, diterate, 2, 0.1, dzero, dzero, 2);
+  launch_solve(scheme, form, 0, batch, stream, dp, g, ws, 1000, -1.0);
+  hipLaunchKernelGGL(p_probe_rows_out, ng, dim3(WAVE), 0, stream, dp, batch, g, (const double *)ws, ddefects, djac, dhess);
   PCHK2(hipGetLastError());
   return ASCENT_OK;
 }

@@ -25,4 +25,9 @@ int persist_run_nested(const ascent_params *dp, long batch, int scheme, int form
 int persist_probe(const ascent_params *dp, long batch, int scheme, int form, int mp, int K, double *ws, const double *diterate, const double *dmu, const double *ddw,
                   double *dstep, int *dinertia, hipStream_t stream, char *err, size_t errlen);
 
+// The node rows (defects, Jacobian and Hessian blocks in the layout of ascent_eval_nodes) that one round of the same kernel
+// leaves in LDS for its factorisation sweep, copied out instead of swept.  dzero: `batch` zeros on the device.
+int persist_probe_rows(const ascent_params *dp, long batch, int scheme, int form, int K, double *ws, const double *diterate, const double *dzero,
+                       double *ddefects, double *djac, double *dhess, hipStream_t stream, char *err, size_t errlen);
+
 }  // namespace ascent

@@ -1309,8 +1309,9 @@ int ascent_eval_nodes_path(const ascent_params *p, int64_t batch, const ascent_o
   if (rc) return rc;
   if (o->move_penalty) { snprintf(g_err, sizeof g_err, "the parity surfaces take the unpenalised NLP only (move_penalty = 1 is an option of ascent_solve_batch)"); return ASCENT_E_ARG; }
   if (!iterate || !defects || !jac_blocks || !hess_blocks) { snprintf(g_err, sizeof g_err, "null pointer"); return ASCENT_E_ARG; }
-  if (path < ASCENT_PATH_AUTO || path > ASCENT_PATH_DENSE) { snprintf(g_err, sizeof g_err, "unknown path %d", path); return ASCENT_E_ARG; }
-  path = resolve_path(path, o, batch);
+  if (path < ASCENT_PATH_AUTO || path > ASCENT_PATH_PERSIST) { snprintf(g_err, sizeof g_err, "unknown path %d", path); return ASCENT_E_ARG; }
+  path = resolve_path(path, o, batch, true);
+  if (path == ASCENT_PATH_PERSIST && (o->scheme > 1 || (o->scheme == 1 && o->formulation != 0))) { snprintf(g_err, sizeof g_err, "the persistent kernel has schemes 0 and 1 (formulation 1 with scheme 0 only)"); return ASCENT_E_ARG; }
   if (path == ASCENT_PATH_DENSE) { snprintf(g_err, sizeof g_err, "the dense-block path exposes its node evaluation through ascent_dense_records"); return ASCENT_E_ARG; }
   if (o->scheme == 2) { snprintf(g_err, sizeof g_err, "scheme 2 exists in the dense-block path only"); return ASCENT_E_ARG; }
   if (path == ASCENT_PATH_FUSED && (o->scheme != 0 || o->formulation != 0)) { snprintf(g_err, sizeof g_err, "the fused path has scheme 0, formulation 0 only"); return ASCENT_E_ARG; }
@@ -1328,6 +1329,14 @@ int ascent_eval_nodes_path(const ascent_params *p, int64_t batch, const ascent_o
     hipLaunchKernelGGL(k_eval_nodes, dim3((unsigned)((batch + 255) / 256), K), dim3(256), 0, 0, bp.d, (long)batch, K,
                        bit.d, bd.d, bj.d, bh.d);
     HIPCHK(hipGetLastError());
+  } else if (path == ASCENT_PATH_PERSIST) {
+    rc = ensure_ws(g_ws_slot0(device_id), persist_ws_bytes(K, (long)batch, 0));
+    if (rc) return rc;
+    HIPCHK(bz.alloc(batch));
+    HIPCHK(hipMemset(bz.d, 0, batch * sizeof(double)));
+    rc = persist_probe_rows(bp.d, (long)batch, (int)o->scheme, (int)o->formulation, K, g_ws_slot0(device_id).ws, bit.d, bz.d, bd.d, bj.d, bh.d, 0,
+                            g_err, sizeof g_err);
+    if (rc) return rc;
   } else {
     rc = ensure_ws(g_ws_slot0(device_id), pipeline_ws_bytes(K, (long)batch));
     if (rc) return rc;

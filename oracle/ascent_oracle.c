@@ -773,6 +773,7 @@ static int solve_one(const oparams *prm, int nt, int max_iter, double tol, int w
     memset(it.lam, 0, 7 * K * 8); it.sc[S_NU3] = it.sc[S_NU1] = it.sc[S_NU2] = 0.0;
   }
   const double dcw = g_mp ? mp_weight(&d) : 0.0;
+  double mu = (asked_warm && !warm) ? g_mu0 : mu0 > 0.0 ? mu0 : (warm ? 1e-4 : g_mu0), nu_pen = 1.0, dw_last = 0.0;
   if (g_mp) {      /* slacks of the movement equations around the guess's own movement; multipliers that zero their stationarity rows */
     const double eps = warm ? 1e-4 : 1e-2;
     for (int k = 0; k < K; k++) {
@@ -780,7 +781,6 @@ static int solve_one(const oparams *prm, int nt, int max_iter, double tol, int w
       it.lu[k] = 0.0; it.pp[k] = fmax(dl, 0.0) + eps; it.pn[k] = fmax(-dl, 0.0) + eps; it.zp[k] = it.zn[k] = dcw;
     }
   }
-  double mu = (asked_warm && !warm) ? g_mu0 : mu0 > 0.0 ? mu0 : (warm ? 1e-4 : g_mu0), nu_pen = 1.0, dw_last = 0.0;
   int status = ST_MAXITER, iters = 0, nreg = 0;
   for (int iter = 0; iter < max_iter; iter++) {
     double e0 = kkt_error(&d, w, &it, 0.0);

@@ -7,7 +7,9 @@ import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lunar_module_ascent_trajectory_optimiser_amd as A
 B = int(os.environ.get("PROF_BATCH", "4096"))
+MP = os.environ.get("PROF_MP", "1") == "1"        # the bench's default model: with the reference's DCOST = 1e-5 (PROF_MP=0: without)
 S = A.sweep_isp_drymass()[:: max(1, 4096 // B)][:B] if B <= 4096 else A.sweep_config4()[:B]
+S[:, 15] = 1e-5
 for _ in range(int(os.environ.get("PROF_N", "3"))):
-    r = A.solve_batch(S, 200, tol=1e-9)
-print("path", A.default_path(B, 200), "iters", r.iters.mean(), "converged", (r.status == 0).sum(), "kernel ms", A.last_kernel_ms())
+    r = A.solve_batch(S, 200, tol=1e-9, move_penalty=MP)
+print("move_penalty", MP, "path", A.default_path(B, 200, move_penalty=MP), "iters", r.iters.mean(), "converged", (r.status == 0).sum(), "kernel ms", A.last_kernel_ms())

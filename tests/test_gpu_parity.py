@@ -70,11 +70,13 @@ def _interior_blobs(coracle, S, nt, scheme, form):
     return np.stack(blobs, axis=1)
 
 
-@pytest.mark.parametrize("path,scheme,form", STEP_CASES)
+@pytest.mark.parametrize("path,scheme,form", STEP_CASES + [("persist", 0, 0), ("persist", 1, 0), ("persist", 0, 1)])
 def test_eval_nodes_matches_oracle(coracle, path, scheme, form):
     """Defects and Jacobian/Hessian blocks of every step (Launch_Optimiser.py:114-136), 1e-12 relative, through the
-    kernels each solver path really runs: "fused" = k_eval_nodes, "split_*" = q_trial_eval (the kernel the bench
-    headline times), whose materialised rows Q_C / Q_G / Q_H come back through q_probe_out."""
+    kernels each solver path really runs: "fused" = k_eval_nodes, "split_*" = q_trial_eval, whose materialised rows
+    Q_C / Q_G / Q_H come back through q_probe_out, "persist" = p_solve (the kernel the bench headline times): the rows its
+    node-parallel phase stages in LDS for the factorisation sweep (S_G / S_H / S_C), copied out of LDS by the kernel itself
+    before the sweep would read them (probe kind 2) -- a wrong Jacobian row there is localised, not just a step mismatch."""
     base = A.AscentParams(**V1) if form else A.AscentParams()
     S = A.sweep_isp_drymass(2, 2, base=base)
     blobs = _interior_blobs(coracle, S, NT, scheme, form)
