@@ -481,17 +481,20 @@ struct TrialCtx {       // what the trial point of an NLP needs besides the node
 };
 
 // The trial point x + alpha dx at node k (iterate n, step dn), stored into the other iterate buffer, and its pieces of the
-// l1 merit function and of the KKT error (Launch_Optimiser.py:114-136 evaluated once, with first derivatives).
+// l1 merit function and of the KKT error (Launch_Optimiser.py:114-136 evaluated once, with first derivatives) -- in two parts:
+// everything that depends on the primal variables and the bound multipliers only (trial_primal), and the rows that need the
+// equality multipliers of the trial point (trial_dual).  The adjoint phase knows the primal step of a chunk before its sweep and
+// the multiplier step after it: it runs the first part before the sweep and carries TrialKeep (21 values) across it instead of
+// the node's whole iterate and step (70).  Every accumulator of Part sees the same operations in the same order as in one pass.
+struct TrialKeep { double G[8], F[7], dza, dzm, zb4, zb5, zpp, zpn; };
+
 template <int SCHEME, int FORM, int MP = 0>
-ASC_DEV void trial_node(const Der &d, int K, int Kp, int k, const NodeIn &n, const NodeIn &dn, const TrialCtx &t, bool live,
-                        double *in, Part &P) {
+ASC_DEV void trial_primal(const Der &d, int K, int Kp, int k, const NodeIn &n, const NodeIn &dn, const TrialCtx &t, bool live,
+                          double *in, Part &P, TrialKeep &kp) {
   const double alpha = t.alpha;
-  double z[7], zp[7], l[7], ln[7], zb[6];
+  double z[7], zp[7], zb[6];
   ASC_UNROLL
-  for (int i = 0; i < 7; i++) {
-    z[i] = n.z[i] + alpha * dn.z[i]; zp[i] = n.zp[i] + alpha * dn.zp[i];
-    l[i] = n.l[i] + alpha * dn.l[i]; ln[i] = n.ln[i] + alpha * dn.ln[i];
-  }
+  for (int i = 0; i < 7; i++) { z[i] = n.z[i] + alpha * dn.z[i]; zp[i] = n.zp[i] + alpha * dn.zp[i]; }
   const double u = n.u + alpha * dn.u;
   const double dist[6] = {z[IA], d.aub - z[IA], z[IM], 1.0 - z[IM], u + 1.0, 1.0 - u};
   ASC_UNROLL
@@ -501,66 +504,48 @@ ASC_DEV void trial_node(const Der &d, int K, int Kp, int k, const NodeIn &n, con
   }
   if (live) {
     ASC_UNROLL
-    for (int i = 0; i < 7; i++) { in[(O_Z + i) * Kp + k] = z[i]; in[(O_L + i) * Kp + k] = l[i]; }
+    for (int i = 0; i < 7; i++) in[(O_Z + i) * Kp + k] = z[i];
     in[O_U * Kp + k] = u;
     ASC_UNROLL
     for (int b = 0; b < 6; b++) in[(O_ZB + b) * Kp + k] = zb[b];
   }
-  double lu = 0.0, lun = 0.0;
+  kp.zpp = 0.0; kp.zpn = 0.0;
   if constexpr (MP) {      // the movement equation of the step, its slack pair and their rows of the KKT error
     const double up = n.up + alpha * dn.up, pp = n.pp + alpha * dn.pp, pn = n.pn + alpha * dn.pn;
-    lu = n.lu + alpha * dn.lu; lun = n.lun + alpha * dn.lun;
     const double ip = rcp(pp), in_ = rcp(pn);
     const double zpp = t.first ? n.zpp : fmin(fmax(n.zpp + t.adu * dn.zpp, t.mlo * ip), t.mhi * ip);
     const double zpn = t.first ? n.zpn : fmin(fmax(n.zpn + t.adu * dn.zpn, t.mlo * in_), t.mhi * in_);
-    if (live) { in[O_LU * Kp + k] = lu; in[O_PP * Kp + k] = pp; in[O_PN * Kp + k] = pn; in[O_ZP * Kp + k] = zpp; in[O_ZN * Kp + k] = zpn; }
+    if (live) { in[O_PP * Kp + k] = pp; in[O_PN * Kp + k] = pn; in[O_ZP * Kp + k] = zpp; in[O_ZN * Kp + k] = zpn; }
     const double cu = u - up - pp + pn;
     P.c1 += fabs(cu);
     P.cinf = fmax(P.cinf, fabs(cu));
-    P.l1 += fabs(lu);
-    P.rd = fmax(P.rd, fmax(fabs(t.dcw - lu - zpp), fabs(t.dcw + lu - zpn)));
     const double prp = pp * zpp, prn = pn * zpn;
     P.pmin = fmin(P.pmin, fmin(prp, prn)); P.pmax = fmax(P.pmax, fmax(prp, prn));
     P.zsum += zpp + zpn;
     P.mv += pp + pn;
     const double ps = pp * pn;
     P.sl += ps > 0.0 ? log(ps) : NAN;
+    kp.zpp = zpp; kp.zpn = zpn;
   }
-  // (scheme 1, the trapezoid with the control held over the step: defect z_k - z_{k-1} - dt/2 [f(z_k,u_k) + f(z_{k-1},u_k)]; node k then
-  //  carries the multipliers of steps k and k+1 in its stationarity row, each with half the step)
-  const double cs = SCHEME == 1 ? 0.5 * t.dt : t.dt;
-  double G[8], F[7], fl[7], lt[7], ax, ay;
-  accel<1>(d, z[IX], z[IY], z[IA], z[IM], 0.0, 0.0, ax, ay, G, nullptr);
-  rhs_f<FORM>(d, z, u, ax, ay, F);
+  double ax, ay;
+  accel<1>(d, z[IX], z[IY], z[IA], z[IM], 0.0, 0.0, ax, ay, kp.G, nullptr);
+  rhs_f<FORM>(d, z, u, ax, ay, kp.F);
   if (SCHEME == 1) {
     double Fb[7], axp, ayp;
     accel<0>(d, zp[IX], zp[IY], zp[IA], zp[IM], 0.0, 0.0, axp, ayp, nullptr, nullptr);
     rhs_f<FORM>(d, zp, u, axp, ayp, Fb);
     ASC_UNROLL
-    for (int i = 0; i < 7; i++) F[i] = 0.5 * (F[i] + Fb[i]);
+    for (int i = 0; i < 7; i++) kp.F[i] = 0.5 * (kp.F[i] + Fb[i]);
   }
-  ASC_UNROLL
-  for (int i = 0; i < 7; i++) lt[i] = SCHEME == 1 ? l[i] + ln[i] : l[i];
-  fzt_lambda<FORM>(G, lt, fl);
-  double r[7];
   ASC_UNROLL
   for (int i = 0; i < 7; i++) {
-    r[i] = (FORM == 1 && i == IA) ? l[i] - cs * fl[i] : l[i] - cs * fl[i] - ln[i];
-    const double cc = (FORM == 1 && i == IA) ? z[IA] - 0.5 * d.aub * (u + 1.0) : z[i] - zp[i] - t.dt * F[i];
+    const double cc = (FORM == 1 && i == IA) ? z[IA] - 0.5 * d.aub * (u + 1.0) : z[i] - zp[i] - t.dt * kp.F[i];
     P.c1 += fabs(cc);
     P.cinf = fmax(P.cinf, fabs(cc));
-    P.rth -= t.hT * F[i] * l[i];
-    P.l1 += fabs(l[i]);
   }
-  r[IA] += zb[1] - zb[0];
-  r[IM] += zb[3] - zb[2];
   if (k == K - 1) {
     const Scal &stt = t.stt;
     const Terminal tt = terminal_eval(d, z);
-    r[IX] += stt.nu3 * tt.e3g[0] + stt.nu1 * tt.g1g[0];
-    r[IY] += stt.nu3 * tt.e3g[1] + stt.nu1 * tt.g1g[1];
-    r[IVX] += stt.nu3 * tt.e3g[2] + stt.nu2 * tt.g2g[0];
-    r[IVY] += stt.nu3 * tt.e3g[3] + stt.nu2 * tt.g2g[1];
     const double e1 = fabs(tt.e3), e2 = fabs(tt.g1 - stt.s1), e3 = fabs(tt.g2 - stt.s2);
     P.cinf = fmax(P.cinf, fmax(e1, fmax(e2, e3)));
     P.c1 += e1 + e2 + e3;
@@ -568,14 +553,70 @@ ASC_DEV void trial_node(const Der &d, int K, int Kp, int k, const NodeIn &n, con
     P.sl += ps > 0.0 ? log(ps) : NAN;
   }
   ASC_UNROLL
-  for (int i = 0; i < 7; i++) P.rd = fmax(P.rd, fabs(r[i]));
-  double ruv = (FORM == 1 ? -0.5 * d.aub * l[IA] : -t.be * l[IW]) - zb[4] + zb[5];
-  if constexpr (MP) ruv += lu - lun;
-  P.rd = fmax(P.rd, fabs(ruv));
-  ASC_UNROLL
   for (int b = 0; b < 6; b++) { const double pr = dist[b] * zb[b]; P.pmin = fmin(P.pmin, pr); P.pmax = fmax(P.pmax, pr); P.zsum += zb[b]; }
   const double pa = dist[0] * dist[1], pm = dist[2] * dist[3], pu = dist[4] * dist[5];
   P.sl += (pa > 0.0 && pm > 0.0 && pu > 0.0) ? log(pa * pm * pu) : NAN;
+  kp.dza = zb[1] - zb[0]; kp.dzm = zb[3] - zb[2]; kp.zb4 = zb[4]; kp.zb5 = zb[5];
+}
+
+// ... and the rows with the trial multipliers l (node k), ln (node k+1), lu / lun (move penalty: of the movement equations)
+template <int SCHEME, int FORM, int MP = 0>
+ASC_DEV void trial_dual(const Der &d, int K, int Kp, int k, const TrialKeep &kp, const double *l, const double *ln, double lu, double lun,
+                        const TrialCtx &t, bool live, double *in, Part &P) {
+  if (live) {
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) in[(O_L + i) * Kp + k] = l[i];
+    if constexpr (MP) in[O_LU * Kp + k] = lu;
+  }
+  if constexpr (MP) {
+    P.l1 += fabs(lu);
+    P.rd = fmax(P.rd, fmax(fabs(t.dcw - lu - kp.zpp), fabs(t.dcw + lu - kp.zpn)));
+  }
+  // (scheme 1, the trapezoid with the control held over the step: defect z_k - z_{k-1} - dt/2 [f(z_k,u_k) + f(z_{k-1},u_k)]; node k then
+  //  carries the multipliers of steps k and k+1 in its stationarity row, each with half the step)
+  const double cs = SCHEME == 1 ? 0.5 * t.dt : t.dt;
+  double fl[7], lt[7];
+  ASC_UNROLL
+  for (int i = 0; i < 7; i++) lt[i] = SCHEME == 1 ? l[i] + ln[i] : l[i];
+  fzt_lambda<FORM>(kp.G, lt, fl);
+  double r[7];
+  ASC_UNROLL
+  for (int i = 0; i < 7; i++) {
+    r[i] = (FORM == 1 && i == IA) ? l[i] - cs * fl[i] : l[i] - cs * fl[i] - ln[i];
+    P.rth -= t.hT * kp.F[i] * l[i];
+    P.l1 += fabs(l[i]);
+  }
+  r[IA] += kp.dza;
+  r[IM] += kp.dzm;
+  if (k == K - 1) {       // (the last node's trial state comes back from the buffer this lane has just written)
+    const Scal &stt = t.stt;
+    double z[7];
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) z[i] = in[(O_Z + i) * Kp + k];
+    const Terminal tt = terminal_eval(d, z);
+    r[IX] += stt.nu3 * tt.e3g[0] + stt.nu1 * tt.g1g[0];
+    r[IY] += stt.nu3 * tt.e3g[1] + stt.nu1 * tt.g1g[1];
+    r[IVX] += stt.nu3 * tt.e3g[2] + stt.nu2 * tt.g2g[0];
+    r[IVY] += stt.nu3 * tt.e3g[3] + stt.nu2 * tt.g2g[1];
+  }
+  ASC_UNROLL
+  for (int i = 0; i < 7; i++) P.rd = fmax(P.rd, fabs(r[i]));
+  double ruv = (FORM == 1 ? -0.5 * d.aub * l[IA] : -t.be * l[IW]) - kp.zb4 + kp.zb5;
+  if constexpr (MP) ruv += lu - lun;
+  P.rd = fmax(P.rd, fabs(ruv));
+}
+
+// both parts in one go (line-search retries and the first point of a level)
+template <int SCHEME, int FORM, int MP = 0>
+ASC_DEV void trial_node(const Der &d, int K, int Kp, int k, const NodeIn &n, const NodeIn &dn, const TrialCtx &t, bool live,
+                        double *in, Part &P) {
+  TrialKeep kp;
+  trial_primal<SCHEME, FORM, MP>(d, K, Kp, k, n, dn, t, live, in, P, kp);
+  double l[7], ln[7];
+  ASC_UNROLL
+  for (int i = 0; i < 7; i++) { l[i] = n.l[i] + t.alpha * dn.l[i]; ln[i] = n.ln[i] + t.alpha * dn.ln[i]; }
+  const double lu = MP ? n.lu + t.alpha * dn.lu : 0.0, lun = MP ? n.lun + t.alpha * dn.lun : 0.0;
+  trial_dual<SCHEME, FORM, MP>(d, K, Kp, k, kp, l, ln, lu, lun, t, live, in, P);
 }
 
 #ifdef PERSIST_PROFILE      // diagnostic build (scripts/persist_profile.py): shader cycles per phase, wavefront 0
@@ -1331,8 +1372,9 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
         for (int c = nch - 1; c >= 0; c--) {
           const int kn = c * CH + role;
           double ccn[7] = {0, 0, 0, 0, 0, 0, 0};
-          NodeIn n, dn;                       // loaded here, used again for the trial point after the sweep of the chunk
+          TrialKeep kp;                       // what the trial point's dual rows need of its primal part (evaluated before the sweep)
           if (kn < K && act) {
+            NodeIn n, dn;
             load_node<MP>(it, Kp, K, kn, n);
             ASC_UNROLL
             for (int i = 0; i < 7; i++) { dn.z[i] = stp[(O_Z + i) * Kp + kn]; dn.zp[i] = kn > 0 ? stp[(O_Z + i) * Kp + kn - 1] : 0.0; }
@@ -1418,6 +1460,8 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             }
             ASC_UNROLL
             for (int i = 0; i < 7; i++) stage[(6 * i + 5) * LDW + col] = wv[i];
+            // the primal step of the chunk is known: the primal part of its trial point at the first step length, before the sweep
+            trial_primal<SCHEME, FORM, MP>(d, K, Kp, kn, n, dn, tc, live, in, P, kp);
           }
           wsync();
           PROF(7);
@@ -1434,27 +1478,39 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             }
           }
           wsync();
+          double dl[7], dln[7];
           if (kn < K && act) {
             ASC_UNROLL
             for (int i = 0; i < 7; i++) {
-              dn.l[i] = outb[i * LDW + col];
-              dn.ln[i] = kn + 1 < K ? (role < 15 ? outb[i * LDW + col + 1] : lds_c[grp][i]) : 0.0;
-              ccl += ccn[i] * dn.l[i];            // c . dlambda: no recurrence, summed here
+              dl[i] = outb[i * LDW + col];
+              dln[i] = kn + 1 < K ? (role < 15 ? outb[i * LDW + col + 1] : lds_c[grp][i]) : 0.0;
+              ccl += ccn[i] * dl[i];            // c . dlambda: no recurrence, summed here
             }
             if (live) {
               ASC_UNROLL
-              for (int i = 0; i < 7; i++) stp[(O_L + i) * Kp + kn] = dn.l[i];
+              for (int i = 0; i < 7; i++) stp[(O_L + i) * Kp + kn] = dl[i];
             }
           }
           wsync();
           PROF(8);
-          // ---- node-parallel: the step of the chunk is complete -> its part of the trial point at the first step length --------
+          // ---- node-parallel: the step of the chunk is complete -> the dual rows of its trial point (the iterate's multipliers
+          //      come from HBM again rather than being held across the sweep) ------------------------------------------------------
           if (kn < K && act) {
             if (role == 0) {
               ASC_UNROLL
-              for (int i = 0; i < 7; i++) lds_c[grp][i] = dn.l[i];
+              for (int i = 0; i < 7; i++) lds_c[grp][i] = dl[i];
             }
-            trial_node<SCHEME, FORM, MP>(d, K, Kp, kn, n, dn, tc, live, in, P);
+            double l[7], ln[7], lu = 0.0, lun = 0.0;
+            ASC_UNROLL
+            for (int i = 0; i < 7; i++) {
+              l[i] = it[(O_L + i) * Kp + kn] + tc.alpha * dl[i];
+              ln[i] = (kn + 1 < K ? it[(O_L + i) * Kp + kn + 1] : 0.0) + tc.alpha * dln[i];
+            }
+            if constexpr (MP) {
+              lu = it[O_LU * Kp + kn] + tc.alpha * stp[O_LU * Kp + kn];
+              lun = (kn + 1 < K ? it[O_LU * Kp + kn + 1] : 0.0) + tc.alpha * (kn + 1 < K ? stp[O_LU * Kp + kn + 1] : 0.0);
+            }
+            trial_dual<SCHEME, FORM, MP>(d, K, Kp, kn, kp, l, ln, lu, lun, tc, live, in, P);
           }
           PROF(0);
         }
