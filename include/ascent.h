@@ -73,7 +73,12 @@ typedef struct ascent_opts {
                                r_peri with r.v = 0, :158-173);
                            1 = the (r_peri, r_apo) ellipse proper (README.md:7): same three constraints with the vis-viva
                                speed at the periapsis of that ellipse, so that the burnout orbit is the target ellipse and
-                               ascent_coast_batch's coast arc ends at its apoapsis                          */
+                               ascent_coast_batch's coast arc ends at its apoapsis;
+                           2 = burnout ANYWHERE on that ellipse -- the burn--coast problem of BASELINE config 5 with the coast
+                               arc eliminated exactly (two-body motion): two conditions, angular momentum >= and specific energy
+                               <= those of the ellipse (an orbit nested in the target annulus; both active at the optimum), no
+                               r.v = 0; ascent_coast_batch continues from whatever true anomaly the burn ends at.
+                               Dense-block path (any scheme, formulation 0)                                   */
   int32_t solver_path;  /* 0 = automatic (hand-tuned sparse kernels for schemes 0/1, dense-block path for scheme 2);
                            ASCENT_PATH_DENSE = the dense-block path for any scheme (formulation 0 only)       */
   int32_t move_penalty; /* 0 = ascent_params.dcost is ignored (the default: the penalty moves the reference's t_f by 3.5e-6

@@ -85,12 +85,20 @@ struct DGeo {
 // (vis-viva speed at the periapsis of the (r_peri, r_apo) ellipse)
 ASC_DEV Der derive_t(const ascent_params &p, int terminal) {
   Der d = derive(p);
-  if (terminal == 1) {
+  if (terminal == 1 || terminal == 2) {
     const double S = p.r_peri, GM = p.G * p.M, rp = p.R0 + p.r_peri, ra = p.R0 + p.r_apo;
-    d.vp2 = GM * (2.0 / rp - 2.0 / (ra + rp)) / (S * S);
+    d.vp2 = GM * (2.0 / rp - 2.0 / (ra + rp)) / (S * S);      // (terminal 2: the cold start still aims at the periapsis)
+    if (terminal == 2) {       // burnout anywhere on that ellipse: its angular momentum and specific energy, scaled units
+      const double rps = rp / S, ras = ra / S;
+      d.term = 2;
+      d.ht = sqrt(2.0 * d.gam * rps * ras / (rps + ras));
+      d.Et = -d.gam / (rps + ras);
+    }
   }
   return d;
 }
+
+ASC_DEV Terminal terminal_of(const Der &d, const double *z) { return d.term == 2 ? terminal_eval_any(d, z) : terminal_eval(d, z); }
 
 ASC_DEV Scal load_scal(const double *sc, int r0) {
   Scal s;
@@ -182,7 +190,7 @@ __global__ __launch_bounds__(WAVE) void d_init(const ascent_params *params, long
     s.th = tf0;
   }
   if (!probe) s.th = push_in(s.th, d.tlb, d.tub);
-  const Terminal tm = terminal_eval(d, z);
+  const Terminal tm = terminal_of(d, z);
   if (probe) {
   } else if (warm != 2) {
     s.s1 = fmax(tm.g1, 1e-2); s.s2 = fmax(tm.g2, 1e-2);
@@ -453,7 +461,7 @@ __global__ __launch_bounds__(WAVE) void d_eval(const ascent_params *params, long
     sl += (pp > 0.0 && pn > 0.0) ? log(pp * pn) : NAN;
   }
   if (k == K - 1) {
-    const Terminal t = terminal_eval(d, zb);
+    const Terminal t = terminal_of(d, zb);
     const double e1 = fabs(t.e3), e2 = fabs(t.g1 - stt.s1), e3 = fabs(t.g2 - stt.s2);
     cinf = fmax(cinf, fmax(e1, fmax(e2, e3)));
     c1 += e1 + e2 + e3;
@@ -605,14 +613,18 @@ __global__ __launch_bounds__(WAVE, PIPE ? 1 : 2) void d_newton(const ascent_para
   const double *it = w + g.off_it(cur);
   // dual residual: node k collects Jb_k'lambda_k + Ja_{k+1}'lambda_{k+1} and its bound multipliers
   double rd = 0.0;
-  const Terminal tm = [&]() { double zK[7]; for (int q = 0; q < 7; q++) zK[q] = it[(O_Z + q) * K + K - 1]; return terminal_eval(d, zK); }();
+  const Terminal tm = [&]() { double zK[7]; for (int q = 0; q < 7; q++) zK[q] = it[(O_Z + q) * K + K - 1]; return terminal_of(d, zK); }();
   for (int k = l; k < K; k += WAVE) {
     double r[7];
     ASC_UNROLL
     for (int q = 0; q < 7; q++) r[q] = nv[(NV_GB + q) * K + k] + (k + 1 < K ? nv[(NV_GA + q) * K + k + 1] : 0.0);
     r[IA] += it[(O_ZB + 1) * K + k] - it[(O_ZB + 0) * K + k];
     r[IM] += it[(O_ZB + 3) * K + k] - it[(O_ZB + 2) * K + k];
-    if (k == K - 1) {
+    if (k == K - 1 && d.term == 2) {
+      double g4[4];
+      terminal_grad_any(tm, s.nu1, s.nu2, g4);
+      r[IX] += g4[0]; r[IY] += g4[1]; r[IVX] += g4[2]; r[IVY] += g4[3];
+    } else if (k == K - 1) {
       r[IX] += s.nu3 * tm.e3g[0] + s.nu1 * tm.g1g[0];
       r[IY] += s.nu3 * tm.e3g[1] + s.nu1 * tm.g1g[1];
       r[IVX] += s.nu3 * tm.e3g[2] + s.nu2 * tm.g2g[0];
@@ -693,14 +705,16 @@ __global__ __launch_bounds__(WAVE, PIPE ? 1 : 2) void d_newton(const ascent_para
       double QT[28];
       ASC_UNROLL
       for (int q = 0; q < 28; q++) QT[q] = 0.0;
-      terminal_hessian(QT, tm, s.nu3, s.nu1, s.nu2, sig1, sig2);
+      if (d.term == 2) terminal_hessian_any(QT, tm, s.nu1, s.nu2, sig1, sig2);
+      else terminal_hessian(QT, tm, s.nu3, s.nu1, s.nu2, sig1, sig2);
       ASC_UNROLL
       for (int a = 0; a < 4; a++) {
         ASC_UNROLL
         for (int b = 0; b < 4; b++) term_add = (i == a && j == b) ? QT[sid(a, b)] : term_add;
       }
-      const double rt4[4] = {s.nu3 * tm.e3g[0] + w1 * tm.g1g[0], s.nu3 * tm.e3g[1] + w1 * tm.g1g[1],
-                             s.nu3 * tm.e3g[2] + w2 * tm.g2g[0], s.nu3 * tm.e3g[3] + w2 * tm.g2g[1]};
+      double rt4[4] = {s.nu3 * tm.e3g[0] + w1 * tm.g1g[0], s.nu3 * tm.e3g[1] + w1 * tm.g1g[1],
+                       s.nu3 * tm.e3g[2] + w2 * tm.g2g[0], s.nu3 * tm.e3g[3] + w2 * tm.g2g[1]};
+      if (d.term == 2) terminal_grad_any(tm, w1, w2, rt4);
       ASC_UNROLL
       for (int a = 0; a < 4; a++) { term_rt = i == a ? rt4[a] : term_rt; term_e3 = i == a ? tm.e3g[a] : term_e3; }
     }
@@ -809,7 +823,7 @@ __global__ __launch_bounds__(WAVE, PIPE ? 1 : 2) void d_newton(const ascent_para
     if (ok) {
       const double itl = rcp(s.th - d.tlb), itu = rcp(d.tub - s.th);
       const double rthp = rth + mu * (itu - itl);
-      const double a11 = s.zlt * itl + s.zut * itu + dw + B.Oth, a12 = B.Otn, a22 = B.Onn;
+      const double a11 = s.zlt * itl + s.zut * itu + dw + B.Oth, a12 = B.Otn, a22 = d.term == 2 ? -1.0 : B.Onn;    // (terminal 2: no r.v = 0; a unit pivot closes the nu3 row)
       const double b1 = -(rthp + B.oth), b2 = -B.onu;
       const double det = a11 * a22 - a12 * a12;
       if (det < 0.0) {
@@ -923,6 +937,10 @@ __global__ __launch_bounds__(WAVE, PIPE ? 1 : 2) void d_newton(const ascent_para
   ds.th = dth; ds.nu3 = dnu3;
   ds.s1 = (tm.g1 - s.s1) + tm.g1g[0] * dzKx + tm.g1g[1] * dzKy;
   ds.s2 = (tm.g2 - s.s2) + tm.g2g[0] * dzKvx + tm.g2g[1] * dzKvy;
+  if (d.term == 2) {
+    ds.s1 += tm.g1v[0] * dzKvx + tm.g1v[1] * dzKvy;
+    ds.s2 += tm.g2p[0] * dzKx + tm.g2p[1] * dzKy;
+  }
   ds.nu1 = sig1 * ds.s1 + rs1;
   ds.nu2 = sig2 * ds.s2 + rs2;
   ds.zs1 = mu / s.s1 - s.zs1 - s.zs1 / s.s1 * ds.s1;
@@ -997,7 +1015,7 @@ __global__ __launch_bounds__(WAVE) void pc_assemble(const ascent_params *params,
   if (last) {
     double zK[7];
     for (int q = 0; q < 7; q++) zK[q] = it[(O_Z + q) * K + K - 1];
-    const Terminal tm = terminal_eval(d, zK);
+    const Terminal tm = terminal_of(d, zK);
     const double is1 = rcp(s.s1), is2 = rcp(s.s2);
     const double sig1 = s.zs1 * is1 + dw, sig2 = s.zs2 * is2 + dw, rs1 = -mu * is1 - s.nu1, rs2 = -mu * is2 - s.nu2;
     const double w1 = s.nu1 + sig1 * (tm.g1 - s.s1) + rs1, w2 = s.nu2 + sig2 * (tm.g2 - s.s2) + rs2;
@@ -1149,7 +1167,7 @@ __global__ __launch_bounds__(WAVE) void pc_step(const ascent_params *params, lon
   const double dcw = DC ? params[p].dcost : 0.0, mv = DC ? sc[X_MV] : 0.0;
   double zK[7];
   for (int q = 0; q < 7; q++) zK[q] = it[(O_Z + q) * K + K - 1];
-  const Terminal tm = terminal_eval(d, zK);
+  const Terminal tm = terminal_of(d, zK);
   // ---- Schur complement of the two border unknowns (theta, nu3) ---------------------------------------------------------
   double hth = 0.0, s11 = 0.0, s12 = 0.0, s21 = 0.0, s22 = 0.0, t1 = 0.0, t2 = 0.0;
   for (int k = l; k < K; k += WAVE) {

@@ -61,6 +61,10 @@ ASC_DEV void sincos_bounded(double x, double &s, double &c) {
 
 struct Der {  // constants derived from ascent_params (Launch_Optimiser.py:65,72-75,107-109)
   double rho0, rhof, vp2, gam, thr, alpha, mrate, ms, M0, T, aub, tlb, tub;
+  // ascent_opts.terminal = 2 (dense-block path): burnout anywhere on the (r_peri, r_apo) ellipse -- its angular momentum and
+  // specific energy in scaled units; term = 0 otherwise (the three constraints of Launch_Optimiser.py:158-173)
+  int term;
+  double ht, Et;
 };
 
 ASC_DEV Der derive(const ascent_params &p) {
@@ -81,6 +85,7 @@ ASC_DEV Der derive(const ascent_params &p) {
   d.aub = p.angle_ub;
   d.tlb = p.tf_lb;
   d.tub = p.tf_ub;
+  d.term = 0; d.ht = 0.0; d.Et = 0.0;
   return d;
 }
 
@@ -318,6 +323,10 @@ struct Terminal {
   double g1g[2];            // d g1 / d(x,y)
   double g2g[2];            // d g2 / d(xdot,ydot)
   double hxx, hxy, hyy;     // second derivatives of g1
+  // Der::term == 2 only (terminal_eval_any): both conditions depend on position and velocity
+  double g1v[2];            // d g1 / d(xdot,ydot)
+  double g2p[2];            // d g2 / d(x,y)
+  double qxx, qxy, qyy;     // position block of the Hessian of g2
 };
 
 ASC_DEV Terminal terminal_eval(const Der &d, const double *z) {
@@ -341,6 +350,54 @@ ASC_DEV Terminal terminal_eval(const Der &d, const double *z) {
   t.hxy = -ex * ey * ir;
   t.hyy = ex * ex * ir;
   return t;
+}
+
+// Der::term == 2: burnout anywhere on the (r_peri, r_apo) ellipse (README.md:7) instead of Launch_Optimiser.py:158-173's
+// three conditions at its periapsis -- two conditions, each an inequality with a slack like the reference's own two, both
+// active at the optimum:
+//   g1 = h - h_t - s1 = 0,  h = x ydot - (y+rho0) xdot   (angular momentum not below the ellipse's)
+//   g2 = E_t - E - s2 = 0,  E = (xdot^2+ydot^2)/2 - gam/rho   (specific energy not above the ellipse's)
+// i.e. an orbit nested in the target annulus (periapsis not lower, apoapsis not higher).  There is no r.v = 0: e3 = 0 with
+// zero gradient, its multiplier nu3 stays where it is (the border's nu3 row is closed with a unit pivot).
+ASC_DEV Terminal terminal_eval_any(const Der &d, const double *z) {
+  Terminal t;
+  const double et = z[IY] + d.rho0;
+  const double r2 = z[IX] * z[IX] + et * et;
+  const double ir = rsqrt(r2);
+  const double ex = z[IX] * ir, ey = et * ir;
+  const double g3 = d.gam * ir * ir * ir;
+  t.e3 = 0.0;
+  t.e3g[0] = t.e3g[1] = t.e3g[2] = t.e3g[3] = 0.0;
+  t.g1 = z[IX] * z[IVY] - et * z[IVX] - d.ht;
+  t.g1g[0] = z[IVY]; t.g1g[1] = -z[IVX]; t.g1v[0] = -et; t.g1v[1] = z[IX];
+  t.hxx = t.hxy = t.hyy = 0.0;
+  t.g2 = d.Et - (0.5 * (z[IVX] * z[IVX] + z[IVY] * z[IVY]) - d.gam * ir);
+  t.g2p[0] = -g3 * z[IX]; t.g2p[1] = -g3 * et; t.g2g[0] = -z[IVX]; t.g2g[1] = -z[IVY];
+  t.qxx = -g3 * (1.0 - 3.0 * ex * ex); t.qxy = 3.0 * g3 * ex * ey; t.qyy = -g3 * (1.0 - 3.0 * ey * ey);
+  return t;
+}
+// gradient of a1 g1 + a2 g2 with respect to (x, y, xdot, ydot)
+ASC_DEV void terminal_grad_any(const Terminal &t, double a1, double a2, double *g) {
+  g[0] = a1 * t.g1g[0] + a2 * t.g2p[0];
+  g[1] = a1 * t.g1g[1] + a2 * t.g2p[1];
+  g[2] = a1 * t.g1v[0] + a2 * t.g2g[0];
+  g[3] = a1 * t.g1v[1] + a2 * t.g2g[1];
+}
+// ... its terminal Lagrangian Hessian and slack-eliminated barrier terms (the counterpart of terminal_hessian below)
+ASC_DEV void terminal_hessian_any(double *Q, const Terminal &t, double nu1, double nu2, double sig1, double sig2) {
+  const double G1[4] = {t.g1g[0], t.g1g[1], t.g1v[0], t.g1v[1]}, G2[4] = {t.g2p[0], t.g2p[1], t.g2g[0], t.g2g[1]};
+  ASC_UNROLL
+  for (int i = 0; i < 4; i++) {
+    ASC_UNROLL
+    for (int j = i; j < 4; j++) Q[sid(i, j)] += sig1 * G1[i] * G1[j] + sig2 * G2[i] * G2[j];
+  }
+  Q[sid(IX, IX)] += nu2 * t.qxx;
+  Q[sid(IX, IY)] += nu2 * t.qxy;
+  Q[sid(IY, IY)] += nu2 * t.qyy;
+  Q[sid(IVX, IVX)] -= nu2;
+  Q[sid(IVY, IVY)] -= nu2;
+  Q[sid(IX, IVY)] += nu1;
+  Q[sid(IY, IVX)] -= nu1;
 }
 
 // adds the terminal Lagrangian Hessian and the slack-eliminated barrier terms to the last node's Q

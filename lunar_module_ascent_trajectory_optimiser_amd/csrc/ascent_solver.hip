@@ -924,7 +924,7 @@ __global__ __launch_bounds__(WAVE) void k_terminal_params(const ascent_params *i
 }
 
 bool use_dense_path(const ascent_opts *o, int64_t batch) {
-  if (o->scheme == 2 || o->solver_path == ASCENT_PATH_DENSE) return true;
+  if (o->scheme == 2 || o->solver_path == ASCENT_PATH_DENSE || o->terminal == 2) return true;
   const char *e = getenv("ASCENT_PIPELINE");
   // (the move penalty exists in the persistent kernel and in the dense-block path: an override that names any other family means the dense one)
   if (o->move_penalty && ((e && strcmp(e, "persist")) || getenv("ASCENT_FACTOR"))) return true;
@@ -1065,7 +1065,8 @@ int check_common(const ascent_params *p, int64_t batch, const ascent_opts *o, in
   if (o->formulation == 1 && o->scheme != 0 && o->scheme != 2) { snprintf(g_err, sizeof g_err, "formulation 1 is available with scheme 0 only"); return ASCENT_E_ARG; }
   if (o->coarse_nodes != -1 && o->coarse_nodes != 0 && (o->coarse_nodes < 3 || o->coarse_nodes >= o->n_nodes)) { snprintf(g_err, sizeof g_err, "coarse_nodes must be -1 (off), 0 (automatic) or in [3, n_nodes)"); return ASCENT_E_ARG; }
   if (o->scheme < 0 || o->scheme > 2) { snprintf(g_err, sizeof g_err, "scheme %d not supported (0 = backward Euler, the reference's NODES=2; 1 = trapezoid; 2 = Hermite-Simpson)", o->scheme); return ASCENT_E_ARG; }
-  if (o->terminal != 0 && o->terminal != 1) { snprintf(g_err, sizeof g_err, "terminal %d not supported (0 = reference, 1 = ellipse proper)", o->terminal); return ASCENT_E_ARG; }
+  if (o->terminal < 0 || o->terminal > 2) { snprintf(g_err, sizeof g_err, "terminal %d not supported (0 = reference, 1 = periapsis of the ellipse, 2 = anywhere on the ellipse)", o->terminal); return ASCENT_E_ARG; }
+  if (o->terminal == 2 && o->formulation != 0) { snprintf(g_err, sizeof g_err, "terminal 2 (the dense-block path) has formulation 0 only"); return ASCENT_E_ARG; }
   if (o->solver_path != ASCENT_PATH_AUTO && o->solver_path != ASCENT_PATH_DENSE) { snprintf(g_err, sizeof g_err, "solver_path must be 0 (automatic) or ASCENT_PATH_DENSE"); return ASCENT_E_ARG; }
   if ((o->scheme == 2 || o->solver_path == ASCENT_PATH_DENSE) && o->formulation != 0) { snprintf(g_err, sizeof g_err, "the dense-block path (scheme 2 / ASCENT_PATH_DENSE) has formulation 0 only"); return ASCENT_E_ARG; }
   if (o->move_penalty && o->formulation != 0) { snprintf(g_err, sizeof g_err, "move_penalty = 1 is carried for formulation 0 only"); return ASCENT_E_ARG; }
@@ -1164,7 +1165,7 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
   const size_t rows = 21 * (size_t)K + NSC;
   const int lpt = lanes_per_tile(batch);
   const bool dense = use_dense_path(o, batch);
-  const bool pcr = dense && use_pcr_newton(batch, o->move_penalty != 0);
+  const bool pcr = dense && o->terminal != 2 && use_pcr_newton(batch, o->move_penalty != 0);     // (terminal 2: the Riccati form carries it)
   const bool persist = !dense && use_persist_path(o, batch);
   const bool split = o->scheme == 1 || o->formulation == 1 || use_split_pipeline(batch);
   int levels[8];
@@ -1237,7 +1238,7 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
     double *traj_l = fin ? dtraj : nullptr, *tf_l = fin ? dtf : w.tfc, *blob_l = fin ? dblob : w.sol;
     int *st_l = fin ? dstatus : w.st_c, *it_l = fin ? diters : w.it_c;
     if (dense) {
-      rc = dense_run(dp, (long)batch, Kl, (int)o->scheme, 0, w.ws, g_l, warm_l, (int)o->max_iter, tol_l, mu_l, traj_l, tf_l, st_l,
+      rc = dense_run(dp, (long)batch, Kl, (int)o->scheme, o->terminal == 2 ? 2 : 0, w.ws, g_l, warm_l, (int)o->max_iter, tol_l, mu_l, traj_l, tf_l, st_l,
                      it_l, blob_l, stream, g_err, sizeof g_err, pcr ? 1 : 0, (int)o->move_penalty);
       if (rc) return rc;
     } else if (split) {
@@ -1378,7 +1379,8 @@ int ascent_kkt_step_path(const ascent_params *p, int64_t batch, const ascent_opt
   const int K = o->n_nodes - 1;
   const size_t rows = 21 * (size_t)K + NSC;
   const int lpt = lanes_per_tile(batch);
-  const bool pcr_probe = path == ASCENT_PATH_DENSE && use_pcr_newton(batch, o->move_penalty != 0);
+  const bool pcr_probe = path == ASCENT_PATH_DENSE && o->terminal != 2 && use_pcr_newton(batch, o->move_penalty != 0);
+  if (o->terminal == 2 && path != ASCENT_PATH_DENSE) { snprintf(g_err, sizeof g_err, "terminal 2 exists in the dense-block path only"); return ASCENT_E_ARG; }
   rc = ensure_ws(g_ws_slot0(device_id), path == ASCENT_PATH_DENSE ? (pcr_probe ? dense_pcr_ws_bytes(K, (long)batch) : dense_ws_bytes(K, (long)batch))
                             : path == ASCENT_PATH_PERSIST ? persist_ws_bytes(K, (long)batch, (int)o->move_penalty) : path == ASCENT_PATH_FUSED ? ws_bytes(K, batch, lpt) : pipeline_ws_bytes(K, (long)batch));
   if (rc) return rc;
@@ -1397,7 +1399,7 @@ int ascent_kkt_step_path(const ascent_params *p, int64_t batch, const ascent_opt
     HIPCHK(hipGetLastError());
   }
   if (path == ASCENT_PATH_DENSE) {
-    rc = dense_probe(bp.d, (long)batch, K, (int)o->scheme, 0, g_ws_slot0(device_id).ws, bit.d, bmu.d, bdw.d, true, bst.d, bin.d, nullptr,
+    rc = dense_probe(bp.d, (long)batch, K, (int)o->scheme, o->terminal == 2 ? 2 : 0, g_ws_slot0(device_id).ws, bit.d, bmu.d, bdw.d, true, bst.d, bin.d, nullptr,
                      0, g_err, sizeof g_err, pcr_probe ? 1 : 0, (int)o->move_penalty);
     if (rc) return rc;
   } else if (path == ASCENT_PATH_PERSIST) {

@@ -20,7 +20,7 @@ def blob_rows(nt: int) -> int:
 
 
 SCHEMES = {"backward_euler": 0, "trapezoid": 1, "hermite_simpson": 2}
-TERMINALS = {"reference": 0, "ellipse": 1}
+TERMINALS = {"reference": 0, "ellipse": 1, "ellipse_free": 2}
 
 
 FORMULATIONS = {"current": 0, "v1": 1}
@@ -115,8 +115,10 @@ def solve_batch(params, nt: int = 200, tol: float = 1e-9, max_iter: int = 300, g
     guess: (21K+10, batch) blob, with warm_start 1 (primal only) or 2 (primal-dual).
     scheme: 0 / "backward_euler" (the reference's NODES=2), 1 / "trapezoid" or 2 / "hermite_simpson" (both with the
     control held over the step; scheme 2 runs on the dense-block solver path).
-    terminal: 0 / "reference" (Launch_Optimiser.py:72-78) or 1 / "ellipse" (the (r_peri, r_apo) ellipse proper: vis-viva
-    speed at its periapsis; `BatchResult.coast()` then ends at its apoapsis).
+    terminal: 0 / "reference" (Launch_Optimiser.py:72-78), 1 / "ellipse" (the (r_peri, r_apo) ellipse proper: vis-viva
+    speed at its periapsis; `BatchResult.coast()` then ends at its apoapsis) or 2 / "ellipse_free" (burnout anywhere on that
+    ellipse: its angular momentum and energy, no r.v = 0; the coast starts at whatever true anomaly the burn ends at;
+    dense-block path).
     path: "auto" or "dense" (the dense-block path for any scheme).
     move_penalty: apply the reference's MV DCOST (Launch_Optimiser.py:99): objective tf + dcost * sum |u_k - u_{k-1}| with the
     `dcost` of each parameter set (schemes 0 / 1: inside the persistent kernel, the control as the eighth state of a stage;

@@ -140,7 +140,12 @@ class GeneralNLP:
             self.in_ = n + self.Kb + np.arange(self.Kb)
             n += 2 * self.Kb
         self.n = n
-        self.m = 7 * self.K + (self.Kb if self.dcost > 0 else 0) + 3
+        # terminal "ellipse": burnout ANYWHERE on the (r_peri, r_apo) ellipse -- two conditions, angular momentum h >= h_t and
+        # specific energy E <= E_t of that ellipse (an orbit nested inside the target annulus: periapsis not lower, apoapsis not
+        # higher; both active at the optimum, like the reference's own radius and speed conditions), and no r.v = 0: the coast
+        # arc that follows is exact two-body motion from whatever true anomaly the burn ends at
+        self.nterm = 2 if self.terminal == "ellipse" else 3
+        self.m = 7 * self.K + (self.Kb if self.dcost > 0 else 0) + self.nterm
         self.rmove = 7 * self.K + np.arange(self.Kb) if self.dcost > 0 else None
         lb = np.full(n, -np.inf)
         ub = np.full(n, np.inf)
@@ -161,6 +166,11 @@ class GeneralNLP:
             ra, rp = P.R0 + P.r_apo, P.R0 + P.r_peri                      # ellipse: LO:158-173 with the vis-viva speed there
             self.rho_t = rp / d["S"]                                      # instead of LO:72-78's circular speed of the mean radius
             self.v2_t = d["GM"] * (2.0 / rp - 2.0 / (ra + rp)) / d["S"] ** 2
+        elif self.terminal == "ellipse":                                  # angular momentum and energy of that ellipse, scaled units
+            ra, rp = (P.R0 + P.r_apo) / d["S"], (P.R0 + P.r_peri) / d["S"]
+            self.h_t = math.sqrt(2.0 * d["gam"] * rp * ra / (rp + ra))
+            self.E_t = -d["gam"] / (rp + ra)
+            self.rho_t, self.v2_t = rp, d["gam"] * (2.0 / rp - 2.0 / (ra + rp))      # (initial guess only)
         else:                                                             # apoapsis of the (r_peri, r_apo) ellipse
             ra, rp = P.R0 + P.r_apo, P.R0 + P.r_peri
             self.rho_t = ra / d["S"]
@@ -225,6 +235,9 @@ class GeneralNLP:
     def terminal_values(self, v):
         zK = self.states(v)[-1]
         eta = zK[Y] + self.d["rho0"]
+        if self.terminal == "ellipse":       # (e3 does not exist): h = X vy - Y vx,  E = |v|^2/2 - gam/rho
+            return (0.0, zK[X] * zK[VY] - eta * zK[VX] - self.h_t,
+                    self.E_t - (0.5 * (zK[VX] ** 2 + zK[VY] ** 2) - self.d["gam"] / math.hypot(zK[X], eta)))
         return (eta * zK[VY] + zK[X] * zK[VX], math.hypot(zK[X], eta) - self.rho_t,
                 zK[VX] ** 2 + zK[VY] ** 2 - self.v2_t)
 
@@ -236,7 +249,9 @@ class GeneralNLP:
             U = v[self.ucol]
             out[self.rmove] = U - np.concatenate([[0.0], U[:-1]]) - v[self.ip] + v[self.in_]
         e3, g1, g2 = self.terminal_values(v)
-        out[-3], out[-2], out[-1] = e3, g1 - v[self.is1], g2 - v[self.is2]
+        if self.nterm == 3:
+            out[-3] = e3
+        out[-2], out[-1] = g1 - v[self.is1], g2 - v[self.is2]
         return out
 
     def jacobian(self, v):
@@ -257,9 +272,15 @@ class GeneralNLP:
         eta = zK[Y] + self.d["rho0"]
         rho = math.hypot(zK[X], eta)
         r3, r1, r2 = self.m - 3, self.m - 2, self.m - 1
-        r += [np.array([r3, r3, r3, r3, r1, r1, r1, r2, r2, r2])]
-        c_ += [np.array([last + X, last + Y, last + VX, last + VY, last + X, last + Y, self.is1, last + VX, last + VY, self.is2])]
-        val += [np.array([zK[VX], zK[VY], zK[X], eta, zK[X] / rho, eta / rho, -1.0, 2 * zK[VX], 2 * zK[VY], -1.0])]
+        if self.terminal == "ellipse":
+            g3 = self.d["gam"] / rho ** 3
+            r += [np.array([r1] * 5 + [r2] * 5)]
+            c_ += [np.array([last + X, last + Y, last + VX, last + VY, self.is1, last + X, last + Y, last + VX, last + VY, self.is2])]
+            val += [np.array([zK[VY], -zK[VX], -eta, zK[X], -1.0, -g3 * zK[X], -g3 * eta, -zK[VX], -zK[VY], -1.0])]
+        else:
+            r += [np.array([r3, r3, r3, r3, r1, r1, r1, r2, r2, r2])]
+            c_ += [np.array([last + X, last + Y, last + VX, last + VY, last + X, last + Y, self.is1, last + VX, last + VY, self.is2])]
+            val += [np.array([zK[VX], zK[VY], zK[X], eta, zK[X] / rho, eta / rho, -1.0, 2 * zK[VX], 2 * zK[VY], -1.0])]
         return sp.csc_matrix((np.concatenate(val), (np.concatenate(r), np.concatenate(c_))), shape=(self.m, self.n))
 
     def hessian(self, v, lam):
@@ -270,13 +291,19 @@ class GeneralNLP:
         ok = (ri >= 0) & (ci >= 0) & (H != 0.0)
         r, c_, val = [ri[ok]], [ci[ok]], [H[ok]]
         last = self.col[-1]
-        nu3, nu1, nu2 = lam[-3], lam[-2], lam[-1]
+        nu3, nu1, nu2 = (lam[-3] if self.nterm == 3 else 0.0), lam[-2], lam[-1]
         zK = self.states(v)[-1]
         eta = zK[Y] + self.d["rho0"]
         rho = math.hypot(zK[X], eta)
         ex, ey = zK[X] / rho, eta / rho
-        tr = [(X, X, nu1 * ey * ey / rho), (X, Y, -nu1 * ex * ey / rho), (Y, X, -nu1 * ex * ey / rho), (Y, Y, nu1 * ex * ex / rho),
-              (VX, VX, 2 * nu2), (VY, VY, 2 * nu2), (X, VX, nu3), (VX, X, nu3), (Y, VY, nu3), (VY, Y, nu3)]
+        if self.terminal == "ellipse":      # nu1 * Hessian of h (the antisymmetric position-velocity pattern) + nu2 * Hessian of E
+            g3 = self.d["gam"] / rho ** 3
+            tr = [(X, VY, nu1), (VY, X, nu1), (Y, VX, -nu1), (VX, Y, -nu1),
+                  (X, X, -nu2 * g3 * (1 - 3 * ex * ex)), (X, Y, 3 * nu2 * g3 * ex * ey), (Y, X, 3 * nu2 * g3 * ex * ey),
+                  (Y, Y, -nu2 * g3 * (1 - 3 * ey * ey)), (VX, VX, -nu2), (VY, VY, -nu2)]
+        else:
+            tr = [(X, X, nu1 * ey * ey / rho), (X, Y, -nu1 * ex * ey / rho), (Y, X, -nu1 * ex * ey / rho), (Y, Y, nu1 * ex * ex / rho),
+                  (VX, VX, 2 * nu2), (VY, VY, 2 * nu2), (X, VX, nu3), (VX, X, nu3), (Y, VY, nu3), (VY, Y, nu3)]
         r.append(np.array([last + a for a, _, _ in tr])); c_.append(np.array([last + b for _, b, _ in tr]))
         val.append(np.array([w for _, _, w in tr]))
         return sp.csc_matrix((np.concatenate(val), (np.concatenate(r), np.concatenate(c_))), shape=(self.n, self.n))

@@ -42,15 +42,19 @@ def main():
     P = Params()
     out = {"_comment": "generalised numpy oracle (oracle/ascent_general.py), tol 1e-10, cold start; made by "
                        "scripts/make_hs_fixtures.py; scaled units as the reference's GEKKO variables", "cases": []}
+    # terminal "ellipse" = ascent_opts.terminal 2: burnout anywhere on the (r_peri, r_apo) ellipse (angular momentum and energy)
     for nt, scheme, terminal in ((50, 2, "reference"), (200, 2, "reference"), (200, 0, "periapsis"), (200, 2, "periapsis"),
-                                 (400, 2, "reference")):
+                                 (400, 2, "reference"), (60, 0, "ellipse"), (200, 0, "ellipse"), (200, 2, "ellipse")):
         out["cases"].append(solve(P, nt, scheme, terminal)[0])
-    if "--n2000" in sys.argv:       # ~10 minutes: BASELINE config 5's grid
+    if "--n2000" in sys.argv:       # ~10 minutes each: BASELINE config 5's grid
         out["cases"].append(solve(P, 2000, 2, "periapsis")[0])
+    if "--n2000-ellipse" in sys.argv:
+        out["cases"].append(solve(P, 2000, 2, "ellipse")[0])
     path = os.path.join(ROOT, "tests", "golden", "hs_fixtures.json")
-    if os.path.exists(path) and "--n2000" not in sys.argv:      # keep an N=2000 case made earlier
+    if os.path.exists(path):      # keep the N=2000 cases made earlier (unless they are being made again)
         old = json.load(open(path))
-        out["cases"] += [c for c in old["cases"] if c["nt"] == 2000]
+        have = {(c["nt"], c["scheme"], c["terminal"]) for c in out["cases"]}
+        out["cases"] += [c for c in old["cases"] if c["nt"] == 2000 and (c["nt"], c["scheme"], c["terminal"]) not in have]
     with open(path, "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", path)

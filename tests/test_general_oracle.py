@@ -144,3 +144,34 @@ def test_dcost_fixture_is_what_the_generator_produces():
     for k in fx["cases"]:
         assert 0.0 < k["on"]["tf"] - k["off"]["tf"] <= k["dcost"] * k["off"]["total_variation"]
         assert k["on"]["total_variation"] < k["off"]["total_variation"]
+
+
+def test_terminal_ellipse_free_burnout_anywhere_on_the_target_ellipse():
+    """terminal "ellipse" of the generalised oracle (= ascent_opts.terminal 2): burnout anywhere on the (r_peri, r_apo) ellipse --
+    angular momentum >= and specific energy <= those of the ellipse, no r.v = 0 -- BASELINE config 5's burn--coast problem
+    with the coast arc eliminated exactly.  Its hand-written terminal Jacobian / Hessian against central differences; the
+    converged burnout orbit is the target ellipse to 1 mm with both conditions active, burnout a few metres off the periapsis,
+    and the burn is never longer than the periapsis insertion's (terminal "periapsis" = ascent_opts.terminal 1)."""
+    P = Params()
+    g = GeneralNLP(P, ((11, "burn"),), 0, terminal="ellipse")
+    assert g.m == 7 * 11 + 2
+    rng = np.random.default_rng(11)
+    v = g.initial_guess() + 0.01 * rng.standard_normal(g.n)
+    lam = rng.standard_normal(g.m)
+    J, H = g.jacobian(v).toarray(), g.hessian(v, lam).toarray()
+    eps = 1e-6
+    for col in range(g.col[-1], g.col[-1] + 4):          # the last node's x, y, xdot, ydot: where the terminal rows live
+        e = np.zeros(g.n); e[col] = eps
+        assert np.abs((g.constraints(v + e) - g.constraints(v - e)) / (2 * eps) - J[:, col]).max() < 1e-7
+        assert np.abs((g.jacobian(v + e).T @ lam - g.jacobian(v - e).T @ lam) / (2 * eps) - H[:, col]).max() < 1e-6
+    res = {}
+    for term in ("periapsis", "ellipse"):
+        nlp = GeneralNLP(P, ((59, "burn"),), 0, terminal=term)
+        v, lam, info = solve_ip(nlp, tol=1e-10, max_iter=500)
+        assert info["status"] == "converged"
+        o = nlp.outputs(v)
+        peri, apo = kepler_elements(P, o["x"][-1], o["y"][-1], o["xdot"][-1], o["ydot"][-1])
+        assert abs(peri - P.r_peri) < 1e-3 and abs(apo - P.r_apo) < 1e-3
+        res[term] = (o["final_time"], lam[-2:], v[nlp.is1], v[nlp.is2])
+    assert 0.0 < res["periapsis"][0] - res["ellipse"][0] < 5e-3                    # 0.3 ms less burn
+    assert np.all(res["ellipse"][1] < -1e-3) and res["ellipse"][2] < 1e-8 and res["ellipse"][3] < 1e-8      # both conditions active

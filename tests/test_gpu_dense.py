@@ -126,7 +126,7 @@ def test_hermite_simpson_matches_independent_fixtures():
     constraints, at N = 200 with the ellipse-proper ones (and at N = 2000 when that fixture has been generated)."""
     by = _fixtures()
     for (nt, scheme, terminal), c in sorted(by.items()):
-        r = A.solve_batch(A.AscentParams(), nt, tol=1e-10, scheme=scheme, terminal="ellipse" if terminal == "periapsis" else "reference",
+        r = A.solve_batch(A.AscentParams(), nt, tol=1e-10, scheme=scheme, terminal={"reference": "reference", "periapsis": "ellipse", "ellipse": "ellipse_free"}[terminal],
                           max_iter=500)
         assert r.status[0] == 0
         assert abs(r.tf[0] - c["tf"]) <= 1e-9, (nt, scheme, terminal, r.tf[0], c["tf"])
@@ -214,6 +214,51 @@ def test_ellipse_terminal_through_the_hand_tuned_kernels(coracle):
     assert np.abs(o["periapsis_alt"] - 17703.0).max() < 0.01 and np.abs(o["apoapsis_alt"] - 88615.0).max() < 0.01
     n = A.solve_batch(A.AscentParams(), 200, tol=1e-10, terminal="ellipse")
     assert abs(n.tf[0] - _fixtures()[(200, 0, "periapsis")]["tf"]) <= 1e-9
+
+
+def test_terminal2_burnout_anywhere_on_the_ellipse_then_coast():
+    """BASELINE config 5's burn--coast problem with the coast arc eliminated exactly (ascent_opts.terminal = 2): burnout ANYWHERE on
+    the (r_peri, r_apo) ellipse -- angular momentum and specific energy of the ellipse, no r.v = 0 -- then the Kepler coast from
+    that anomaly (ascent_coast_batch).  Against the generalised numpy oracle's fixtures (terminal "ellipse": t_f to 1e-9);
+    size-independent properties on a sweep and at N = 2000 Hermite-Simpson: the burnout orbit is the target ellipse to 1 m on
+    every problem, the burn is never longer than the periapsis insertion's (terminal 1), burnout is within 100 m of the periapsis
+    radius but not at it (r.v != 0), the coast from there ends at the apoapsis."""
+    by = _fixtures()
+    n = 0
+    for (nt, scheme, terminal), c in sorted(by.items()):
+        if terminal != "ellipse" or nt > 400:
+            continue
+        r = A.solve_batch(A.AscentParams(), nt, tol=1e-10, scheme=scheme, terminal="ellipse_free", max_iter=500)
+        assert r.status[0] == 0 and abs(r.tf[0] - c["tf"]) <= 1e-9, (nt, scheme, r.tf[0], c["tf"])
+        fs = np.array([r.traj[f][-1, 0] for f in (0, 1, 2, 3, 6, 7, 9)])
+        assert np.abs(fs - np.array(c["final_state"])).max() <= 1e-6
+        n += 1
+    assert n >= 3
+    assert A.default_path(16, 200, scheme=0) == "persist"
+    S = A.sweep_isp_drymass(4, 4)
+    for scheme in (0, 2):
+        r1 = A.solve_batch(S, 200, tol=1e-9, scheme=scheme, terminal="ellipse", max_iter=500)
+        r2 = A.solve_batch(S, 200, tol=1e-9, scheme=scheme, terminal="ellipse_free", max_iter=500)
+        assert np.all(r1.status == 0) and np.all(r2.status == 0)
+        o = r2.orbit()
+        assert np.abs(o["periapsis_alt"] - 17703.0).max() < 1.0 and np.abs(o["apoapsis_alt"] - 88615.0).max() < 1.0
+        assert np.all(r2.tf <= r1.tf + 1e-12) and np.all(r1.tf - r2.tf < 1e-4)
+        assert np.abs(o["flight_path_angle"]).min() > 1e-6
+        c2 = r2.coast(coast_nodes=256)
+        Sx, R0 = 17703.0, 1738100.0
+        Xe, Ye = c2["traj"][0, -1] * Sx, c2["traj"][1, -1] * Sx + R0
+        assert np.abs(np.hypot(Xe, Ye) - R0 - 88615.0).max() < 1.0
+    # config 5's grid: N = 2000 Hermite-Simpson
+    n1 = A.solve_batch(A.AscentParams(), 2000, tol=1e-9, scheme=2, terminal="ellipse", max_iter=500)
+    n2 = A.solve_batch(A.AscentParams(), 2000, tol=1e-9, scheme=2, terminal="ellipse_free", max_iter=500)
+    assert n1.status[0] == 0 and n2.status[0] == 0 and n2.tf[0] <= n1.tf[0] and n1.tf[0] - n2.tf[0] < 1e-4
+    o = n2.orbit()
+    assert abs(o["periapsis_alt"][0] - 17703.0) < 1.0 and abs(o["apoapsis_alt"][0] - 88615.0) < 1.0
+    Xb, Yb = n2.traj[0][-1, 0] * 17703.0, n2.traj[1][-1, 0] * 17703.0 + 1738100.0
+    assert 0.0 < np.hypot(Xb, Yb) - 1738100.0 - 17703.0 < 100.0
+    if (2000, 2, "ellipse") in by:
+        r10 = A.solve_batch(A.AscentParams(), 2000, tol=1e-10, scheme=2, terminal="ellipse_free", max_iter=500)
+        assert r10.status[0] == 0 and abs(r10.tf[0] - by[(2000, 2, "ellipse")]["tf"]) <= 1e-9
 
 
 def test_coast_arc_against_the_closed_form():
