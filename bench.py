@@ -255,12 +255,30 @@ def main():
         achieved = b_alg / (k_ms * 1e-3) / 1e9
         # HBM bytes per solve from the PMC counters (profiles/traffic.json, made by scripts/traffic_from_pmc.py): only if that
         # file was measured on THIS build of the kernels (hash of the csrc sources), otherwise null
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.exists(tpath):
-            tj = json.load(open(tpath)).get(f"batch{B}", {})
-            if tj.get("source_sha16") == source_sha16():
-                traffic = tj.get("hbm_bytes_per_launch")
+        def traffic_of(key):
+            tpath = os.path.join(ROOT, "profiles", "traffic.json")
+            if os.path.exists(tpath):
+                tj = json.load(open(tpath)).get(key, {})
+                if tj.get("source_sha16") == source_sha16():
+                    return tj.get("hbm_bytes_per_launch")
+            return None
+        traffic = traffic_of("config3" if mp else "config3_nodcost") if B == 4096 else None
+
+        def roofline_of(P_, nt_, res, ms, key=None, **kw):
+            """roofline object of a secondary configuration: algorithmic bytes from the iterations taken on every grid level (untimed
+            solves of the coarser grids alone give the split), device time of one solve, PMC traffic of profiles/traffic.json[key]"""
+            lv_ = nested_levels(nt_)
+            cum_ = [res.iters.astype(np.int64)]
+            for n_ in lv_[1:]:
+                cum_.append(A.solve_batch(P_, n_, tol=max(args.tol, 1e-3), want_traj=False, **kw).iters.astype(np.int64))
+            cum_.append(np.zeros_like(cum_[0]))
+            levels_ = [(n_, float((cum_[i] - cum_[i + 1]).sum())) for i, n_ in enumerate(lv_)]
+            b_, f_ = algorithmic_bytes(levels_, len(res.iters), nt_), algorithmic_flops(levels_)
+            ach = b_ / (ms * 1e-3) / 1e9
+            return {"bound": "hbm", "binding": "fp64_issue", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                    "traffic": traffic_of(key) if key else None, "kernel_ms": ms, "algorithmic_bytes_per_launch": b_,
+                    "fp64_frac": f_ / (ms * 1e-3) / 1e12 / FP64_PEAK_TFLOPS,
+                    "iterations_mean_by_grid": {str(n_): it_ / len(res.iters) for n_, it_ in levels_}}
         line = {
             "metric": "solved ascent NLPs/sec (N=200 collocation nodes)",
             "value": conv_all_steps / elapsed,
@@ -383,13 +401,42 @@ def main():
             oc["config4_shard0"] = {"value": float((r4.status == 0).sum()) / (ms4 * 1e-3), "unit": "NLPs/s", "ms_per_solve": ms4,
                                     "converged": int((r4.status == 0).sum()), "of": 32768, "path": A.default_path(32768, NT),
                                     "iterations_min_mean_max": [int(r4.iters.min()), float(r4.iters.mean()), int(r4.iters.max())],
-                                    "what": "first contiguous 32768-NLP shard of the 262144-problem box (one GPU's share at 8 GPUs), no trajectories returned"}
+                                    "roofline": roofline_of(S4, NT, r4, ms4, "config4"),
+                                    "what": "first contiguous 32768-NLP shard of the 262144-problem box (one GPU's share at 8 GPUs), DCOST not applied, no trajectories returned"}
+            S4d = S4.copy(); S4d[:, 15] = args.dcost if args.dcost > 0 else 1e-5
+            r4d, ms4d = timed(lambda: A.solve_batch(S4d, NT, tol=args.tol, want_traj=False, move_penalty=True))
+            oc["config4_shard0_with_dcost"] = {"value": float((r4d.status == 0).sum()) / (ms4d * 1e-3), "unit": "NLPs/s", "ms_per_solve": ms4d,
+                                               "converged": int((r4d.status == 0).sum()), "of": 32768, "path": A.default_path(32768, NT, move_penalty=True),
+                                               "iterations_min_mean_max": [int(r4d.iters.min()), float(r4d.iters.mean()), int(r4d.iters.max())],
+                                               "roofline": roofline_of(S4d, NT, r4d, ms4d, None, move_penalty=True),
+                                               "what": "the same shard with the script's MV DCOST applied as an l1 move penalty"}
+            Sh = P.copy()
+            rh, msh = timed(lambda: A.solve_batch(Sh, NT, tol=args.tol, scheme=2, max_iter=500, want_traj=False))
+            oc["config3_hermite_simpson"] = {"value": float((rh.status == 0).sum()) / (msh * 1e-3), "unit": "NLPs/s", "ms_per_solve": msh,
+                                             "converged": int((rh.status == 0).sum()), "of": len(Sh), "path": A.default_path(len(Sh), NT, scheme=2),
+                                             "iterations_min_mean_max": [int(rh.iters.min()), float(rh.iters.mean()), int(rh.iters.max())],
+                                             "roofline": roofline_of(Sh, NT, rh, msh, "hs4096", scheme=2, max_iter=500),
+                                             "what": "the config-3 sweep with Hermite-Simpson (scheme 2; dense-block path, host-steered rounds), DCOST not applied"}
             r5, ms5 = timed(lambda: A.solve_batch(A.AscentParams(), 2000, tol=args.tol, scheme=2, terminal="ellipse", max_iter=500))
             o5 = r5.orbit()
             oc["config5_single_nlp"] = {"ms_per_solve": ms5, "converged": int((r5.status == 0).sum()), "iterations": int(r5.iters[0]),
                                         "final_time_s": float(r5.final_time()[0]), "path": A.default_path(1, 2000, scheme=2),
                                         "orbit_periapsis_apoapsis_alt_m": [float(o5["periapsis_alt"][0]), float(o5["apoapsis_alt"][0])],
-                                        "what": "N=2000 Hermite-Simpson, terminal condition of the (r_peri, r_apo) ellipse, Kepler coast on the device; angular-acceleration bound active"}
+                                        "roofline": roofline_of(A.AscentParams().as_row()[None], 2000, r5, ms5, "config5_one", scheme=2, terminal="ellipse", max_iter=500),
+                                        "what": "N=2000 Hermite-Simpson, terminal condition of the (r_peri, r_apo) ellipse (terminal 1), Kepler coast on the device; angular-acceleration bound active"}
+            r5f, ms5f = timed(lambda: A.solve_batch(A.AscentParams(), 2000, tol=args.tol, scheme=2, terminal="ellipse_free", max_iter=500), n=1)
+            o5f = r5f.orbit()
+            oc["config5_single_nlp_burnout_anywhere"] = {"ms_per_solve": ms5f, "converged": int((r5f.status == 0).sum()), "iterations": int(r5f.iters[0]),
+                                                         "final_time_s": float(r5f.final_time()[0]), "burn_saved_vs_terminal1_ms": float((r5.final_time()[0] - r5f.final_time()[0]) * 1e3),
+                                                         "orbit_periapsis_apoapsis_alt_m": [float(o5f["periapsis_alt"][0]), float(o5f["apoapsis_alt"][0])],
+                                                         "what": "the same grid with terminal 2: burnout anywhere on the ellipse (angular momentum and energy), the burn--coast problem with the coast arc eliminated exactly; Riccati form of the dense path (one wavefront)"}
+            S5 = A.sweep_isp_drymass(16, 16)
+            r5b, ms5b = timed(lambda: A.solve_batch(S5, 2000, tol=args.tol, scheme=2, terminal="ellipse", max_iter=500, want_traj=False), n=2)
+            oc["config5_batch256"] = {"value": float((r5b.status == 0).sum()) / (ms5b * 1e-3), "unit": "NLPs/s", "ms_per_solve": ms5b,
+                                      "converged": int((r5b.status == 0).sum()), "of": 256, "path": A.default_path(256, 2000, scheme=2),
+                                      "iterations_min_mean_max": [int(r5b.iters.min()), float(r5b.iters.mean()), int(r5b.iters.max())],
+                                      "roofline": roofline_of(S5, 2000, r5b, ms5b, "config5", scheme=2, terminal="ellipse", max_iter=500),
+                                      "what": "256 NLPs (16 x 16 Isp x dry-mass sweep) at N=2000 Hermite-Simpson, terminal 1: config 5 as a batch"}
             line["other_configs"] = oc
         if world == 1 and not args.no_cpu_baseline:
             cb, idx, res = cpu_baseline(P, NT, args.tol, min(args.cpu_sample, B), move_penalty=mp)

@@ -226,7 +226,8 @@ int ascent_coast_batch(const ascent_params *p, int64_t batch, const double *fina
  * border [batch][n_nodes][bs][nb], border_diag [batch][nb][nb], rhs and sol [batch][n_nodes*bs + nb].
  * algo 0: block elimination serial in the node index, one wavefront per system; algo 1: parallel cyclic reduction over
  * the nodes (one wavefront per node, log2(n_nodes) levels).  Blocks are padded to 16x16 and multiplied with
- * v_mfma_f64_16x16x4_f64; no pivoting inside blocks (returns ASCENT_E_ARG "singular pivot" if one vanishes); the
+ * v_mfma_f64_16x16x4_f64; no pivoting inside blocks (returns ASCENT_E_ARG "singular pivot" if one vanishes); cyclic reduction exposes no inertia -- the interior-point solver uses it for a handful of NLPs only
+ * and guards it with a curvature test along the step (a weaker guarantee than the exact inertia of the Riccati recursions); the
  * border is closed by a Schur complement on the host.  The interior-point solver does not call this (it uses a
  * Riccati recursion in the 7x7 value function); ascent_last_kernel_ms reports the device time of the solve. */
 int ascent_kkt_solve(int64_t batch, int32_t n_nodes, int32_t bs, int32_t nb, const double *diag, const double *lower,

@@ -70,7 +70,10 @@ BT_DEV Blk btr(double *lds, const Blk &X) {      // transpose through LDS
 }
 BT_DEV Blk bneg(const Blk &X) { Blk r; r.v = -X.v; return r; }
 // Gauss-Jordan inverse in LDS (no pivoting: the caller's blocks must have non-vanishing leading pivots -- block
-// diagonally dominant test systems; KKT blocks ordered (z, u, lambda) with a positive definite (z,u) part)
+// diagonally dominant test systems; KKT blocks ordered (z, u, lambda) with a positive definite (z,u) part).  Only a vanishing
+// pivot is reported: a threshold relative to the block's largest entry was tried (round 3, 1e-13) and rejects healthy
+// interior-point blocks, whose entries span the barrier's sigma = z/s ~ 1e14 down to pivots of 1e-4; the guard against a
+// wrong step is the caller's curvature test along the step (ascent.h: a weaker guarantee than the exact inertia of the Riccati forms).
 BT_DEV Blk binv(double *lm, double *lv, const Blk &X, int &bad) {
   double m[4], v[4];
   _Pragma("unroll") for (int q = 0; q < 4; q++) { m[q] = X.v[q]; v[q] = brow(q) == bcol() ? 1.0 : 0.0; }

@@ -1001,6 +1001,20 @@ static int slot_for(int dev, hipStream_t s) {       // (under g_mu[dev])
     if (g_ws_stream[dev][i] == s) return i;
   for (int i = 1; i < WS_SLOTS; i++)
     if (!g_ws_stream[dev][i]) { g_ws_stream[dev][i] = s; return i; }
+  for (int i = 1; i < WS_SLOTS; i++) {      // table full: a slot whose last solve has finished goes to the new stream (its old one may be gone)
+    DeviceWs &w = g_wss[dev][i];
+    if (!w.launched || hipEventQuery(w.ev1) == hipSuccess) { g_ws_stream[dev][i] = s; return i; }
+  }
+  return 0;
+}
+
+// The parity surfaces and ascent_kkt_solve run on the null stream in workspace 0, which is also the fallback of caller streams
+// that found no slot of their own: before they touch it they wait for whatever solve was last enqueued there (a non-blocking
+// stream does not synchronise with the null stream by itself), and they become the device's "last solve" for ascent_last_kernel_ms.
+static int claim_slot0(int dev) {                   // (under g_mu[dev])
+  DeviceWs &w = g_wss[dev][0];
+  if (w.launched) HIPCHK(hipEventSynchronize(w.ev1));
+  g_ws_last[dev] = 0;
   return 0;
 }
 
@@ -1318,6 +1332,7 @@ int ascent_eval_nodes_path(const ascent_params *p, int64_t batch, const ascent_o
   if (path == ASCENT_PATH_FUSED && (o->scheme != 0 || o->formulation != 0)) { snprintf(g_err, sizeof g_err, "the fused path has scheme 0, formulation 0 only"); return ASCENT_E_ARG; }
   std::lock_guard<std::mutex> lock(g_mu[device_id]);
   HIPCHK(hipSetDevice(device_id));
+  { const int rc0 = claim_slot0(device_id); if (rc0) return rc0; }
   const int K = o->n_nodes - 1;
   const size_t rows = 21 * (size_t)K + NSC;
   DevBuf<ascent_params> bp;
@@ -1376,6 +1391,7 @@ int ascent_kkt_step_path(const ascent_params *p, int64_t batch, const ascent_opt
   if (path == ASCENT_PATH_FUSED && (o->scheme != 0 || o->formulation != 0)) { snprintf(g_err, sizeof g_err, "the fused path has scheme 0, formulation 0 only"); return ASCENT_E_ARG; }
   std::lock_guard<std::mutex> lock(g_mu[device_id]);
   HIPCHK(hipSetDevice(device_id));
+  { const int rc0 = claim_slot0(device_id); if (rc0) return rc0; }
   const int K = o->n_nodes - 1;
   const size_t rows = 21 * (size_t)K + NSC;
   const int lpt = lanes_per_tile(batch);
@@ -1429,6 +1445,7 @@ int ascent_dense_records(const ascent_params *p, int64_t batch, const ascent_opt
   if (o->formulation != 0) { snprintf(g_err, sizeof g_err, "the dense-block path has formulation 0 only"); return ASCENT_E_ARG; }
   std::lock_guard<std::mutex> lock(g_mu[device_id]);
   HIPCHK(hipSetDevice(device_id));
+  { const int rc0 = claim_slot0(device_id); if (rc0) return rc0; }
   const int K = o->n_nodes - 1;
   const size_t rows = 21 * (size_t)K + NSC, nrec = (size_t)batch * K * 6 * 64;
   rc = ensure_ws(g_ws_slot0(device_id), dense_ws_bytes(K, (long)batch));
@@ -1500,6 +1517,7 @@ int ascent_kkt_solve(int64_t batch, int32_t n, int32_t bs, int32_t nb, const dou
   if (device_id < 0 || device_id >= ndev || device_id >= MAX_DEV) { snprintf(g_err, sizeof g_err, "device %d of %d", device_id, ndev); return ASCENT_E_NODEVICE; }
   std::lock_guard<std::mutex> lock(g_mu[device_id]);
   HIPCHK(hipSetDevice(device_id));
+  { const int rc0 = claim_slot0(device_id); if (rc0) return rc0; }
   int rc = ensure_ws(g_ws_slot0(device_id), blocktri_ws_bytes(n, (long)batch, algo));
   if (rc) return rc;
   DeviceWs &w = g_ws_slot0(device_id);

@@ -12,7 +12,7 @@ reading [row][batch] blobs 512 B per wavefront-instruction (q_*, k_*) keep the f
 import csv, glob, json, os, re, sys
 
 fetch_dir, write_dir, stats_dir, n_solves = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
-key = sys.argv[5] if len(sys.argv) > 5 else "batch4096"
+key = sys.argv[5] if len(sys.argv) > 5 else "config3"      # a PROF_WORKLOAD of scripts/prof_solve.py
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from bench import source_sha16  # noqa: E402  (the stamp bench.py checks before it quotes this file)
@@ -66,7 +66,7 @@ for r in csv.DictReader(open(f)):
                 "ms_per_solve": float(r["TotalDurationNs"]) / 1e6 / n_solves, "percent": float(r["Percentage"])}
 out = {
     "source_sha16": source_sha16(),
-    "workload": "BASELINE.json configs[2] (scripts/prof_solve.py), default dispatch (persistent kernel, three grid levels), cold start, tol 1e-9",
+    "workload": f"scripts/prof_solve.py PROF_WORKLOAD={key}, default dispatch, cold start, tol 1e-9",
     "hbm_bytes_per_launch": (rd + wr) / n_solves, "read_bytes": rd / n_solves, "write_bytes": wr / n_solves,
     "definition": "one launch = one bench step = one whole solve of the batch (all kernels of all rounds)",
     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes; KB*1024; FETCH_SIZE x fetch_factor: 1 for the p_* "

@@ -21,13 +21,14 @@ def _example():
 
 
 def _oracle_solver(P, nt, tol, max_iter, formulation=0, **kw):
-    # (the C oracle has no move penalty: `move_penalty`, which the front door passes for the script's DCOST, is ignored here --
-    #  its effect on t_f is 3.5e-6, below the 1e-4 these CPU tests compare at; the GPU tests run the penalty itself)
+    # (the stand-in for the GPU on the CPU box: the plain-C restatement, with the script's DCOST as the l1 move penalty when the
+    #  front door passes `move_penalty`)
     from oracle import c_oracle
     from lunar_module_ascent_trajectory_optimiser_amd.params import pack
     from lunar_module_ascent_trajectory_optimiser_amd.solver import BatchResult
     P = pack(P)
-    r = c_oracle.solve_batch(P, nt, max_iter, tol, formulation=formulation, scheme=kw.get("scheme", 0))
+    r = c_oracle.solve_batch(P, nt, max_iter, tol, formulation=formulation, scheme=kw.get("scheme", 0),
+                             move_penalty=bool(kw.get("move_penalty", False)) and formulation == 0)
     c_oracle.set_formulation(0); c_oracle.set_scheme(0)
     return BatchResult(P, nt, np.ascontiguousarray(np.moveaxis(r["traj"], 0, 2)), r["tf"], r["status"], r["iters"], None, 0.0)
 
@@ -201,7 +202,8 @@ def test_example_end_to_end_on_gpu(golden):
 
 def test_solver_options_of_the_script_are_honoured(golden):
     """m.options.OTOL / RTOL (Launch_Optimiser.py:31-32) bound the KKT tolerance from above but never loosen it beyond 1e-9 (the
-    banner says so); DCOST (:99) is reported as not applied; NODES other than 2 is refused with a pointer to the
+    banner says so); DCOST (:99) is applied by default (weight convention and 'parity unpinned' stated in the banner, OBJFCNVAL =
+    tf + the penalty) and reported, once, when switched off; NODES other than 2 is refused with a pointer to the
     ASCENT_SCHEME extension, which reaches the trapezoid scheme through the front door."""
     import warnings
     from lunar_module_ascent_trajectory_optimiser_amd.gekko_shim import GEKKO, ModelNotRecognised
@@ -221,8 +223,14 @@ def test_solver_options_of_the_script_are_honoured(golden):
         m.solve(disp=True)
     assert seen["tol"] == 1e-9 and "never looser than 1e-9" in buf.getvalue()
     # the script's DCOST is part of its model: passed on as the move penalty by default, no warning ...
-    assert seen["kw"].get("move_penalty") is True and "DCOST 1.0e-05: applied" in buf.getvalue()
+    assert seen["kw"].get("move_penalty") is True and "DCOST 1.0e-05: applied" in buf.getvalue() and "parity unpinned" in buf.getvalue()
     assert not any("DCOST" in str(x.message) for x in w)
+    tv = np.abs(np.diff(m.result.field("angledoubledot")[:, 0])).sum()
+    assert m.options.OBJFCNVAL == pytest.approx(v["tf"].value[0] + 1e-5 * tv, rel=1e-12) and m.options.OBJFCNVAL > v["tf"].value[0]
+    # a solver hook without **kw gets only the options it declares
+    m2, v2, _ = ex.build(nt=60, solver=lambda P, nt, tol, max_iter, formulation=0: _oracle_solver(P, nt, tol, max_iter, formulation))
+    m2.solve(disp=False)
+    assert abs(v2["tf"].value[0] - v["tf"].value[0]) < 1e-4
     # ... and reported, once, when it is switched off
     m.options.ASCENT_DCOST = 0
     buf = io.StringIO()
@@ -276,14 +284,17 @@ def test_dcost_through_the_front_door(golden):
     m, v, _ = ex.build()
     m.options.ASCENT_DCOST = 0
     m.solve(disp=False)
-    t_off = m.options.OBJFCNVAL
+    t_off = m.options.OBJFCNVAL                                  # (no penalty: the objective is tf)
+    assert t_off == v["tf"].value[0]
     GEKKO._dcost_warned = False
     m.options.ASCENT_DCOST = 1                                   # (the default)
     buf = io.StringIO()
     with redirect_stdout(buf), warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         m.solve(disp=True)
-    t_on = m.options.OBJFCNVAL
+    t_on = v["tf"].value[0]
+    tv = np.abs(np.diff(m.result.field("angledoubledot")[:, 0])).sum()
+    assert m.options.OBJFCNVAL == pytest.approx(t_on + 1e-5 * tv, rel=1e-12)      # the objective that was minimised: tf + DCOST * sum|du|
     assert "DCOST 1.0e-05: applied" in buf.getvalue() and not any("DCOST" in str(x.message) for x in w)
     assert abs(t_on - nominal["on"]["tf"]) <= 2e-8 and abs(t_off - nominal["off"]["tf"]) <= 2e-8
     G = golden["current"]["final_time"]
