@@ -81,25 +81,6 @@ struct DGeo {
   __host__ __device__ size_t off_sc() const { return off_fwd() + (size_t)K * FWD_DOUBLES; }
 };
 
-// terminal constants: the reference's (LO:72-78: circular speed of the mean radius at r_peri) or the ellipse proper
-// (vis-viva speed at the periapsis of the (r_peri, r_apo) ellipse)
-ASC_DEV Der derive_t(const ascent_params &p, int terminal) {
-  Der d = derive(p);
-  if (terminal == 1 || terminal == 2) {
-    const double S = p.r_peri, GM = p.G * p.M, rp = p.R0 + p.r_peri, ra = p.R0 + p.r_apo;
-    d.vp2 = GM * (2.0 / rp - 2.0 / (ra + rp)) / (S * S);      // (terminal 2: the cold start still aims at the periapsis)
-    if (terminal == 2) {       // burnout anywhere on that ellipse: its angular momentum and specific energy, scaled units
-      const double rps = rp / S, ras = ra / S;
-      d.term = 2;
-      d.ht = sqrt(2.0 * d.gam * rps * ras / (rps + ras));
-      d.Et = -d.gam / (rps + ras);
-    }
-  }
-  return d;
-}
-
-ASC_DEV Terminal terminal_of(const Der &d, const double *z) { return d.term == 2 ? terminal_eval_any(d, z) : terminal_eval(d, z); }
-
 ASC_DEV Scal load_scal(const double *sc, int r0) {
   Scal s;
   s.th = sc[r0 + S_TH]; s.zlt = sc[r0 + S_ZLT]; s.zut = sc[r0 + S_ZUT]; s.s1 = sc[r0 + S_S1]; s.s2 = sc[r0 + S_S2];

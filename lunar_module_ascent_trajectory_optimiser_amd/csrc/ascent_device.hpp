@@ -400,6 +400,24 @@ ASC_DEV void terminal_hessian_any(double *Q, const Terminal &t, double nu1, doub
   Q[sid(IY, IVX)] -= nu1;
 }
 
+// terminal constants of ascent_opts.terminal: 0 the reference's (Launch_Optimiser.py:72-78: circular speed of the mean radius
+// at r_peri), 1 the ellipse proper (vis-viva speed at the periapsis of the (r_peri, r_apo) ellipse), 2 anywhere on that ellipse
+ASC_DEV Der derive_t(const ascent_params &p, int terminal) {
+  Der d = derive(p);
+  if (terminal == 1 || terminal == 2) {
+    const double S = p.r_peri, GM = p.G * p.M, rp = p.R0 + p.r_peri, ra = p.R0 + p.r_apo;
+    d.vp2 = GM * (2.0 / rp - 2.0 / (ra + rp)) / (S * S);      // (terminal 2: the cold start still aims at the periapsis)
+    if (terminal == 2) {       // burnout anywhere on that ellipse: its angular momentum and specific energy, scaled units
+      const double rps = rp / S, ras = ra / S;
+      d.term = 2;
+      d.ht = sqrt(2.0 * d.gam * rps * ras / (rps + ras));
+      d.Et = -d.gam / (rps + ras);
+    }
+  }
+  return d;
+}
+ASC_DEV Terminal terminal_of(const Der &d, const double *z) { return d.term == 2 ? terminal_eval_any(d, z) : terminal_eval(d, z); }
+
 // adds the terminal Lagrangian Hessian and the slack-eliminated barrier terms to the last node's Q
 ASC_DEV void terminal_hessian(double *Q, const Terminal &t, double nu3, double nu1, double nu2,
                               double sig1, double sig2) {

@@ -79,7 +79,7 @@ enum {
 enum { ST_TRIAL = 0, ST_FACTOR = 1, ST_FACTORED = 2, ST_DONE = 3 };
 
 struct PGeo {
-  int K, Kp, nch, form, mp;
+  int K, Kp, nch, form, mp, term;      // term: ascent_opts.terminal 2 (burnout anywhere on the ellipse) or 0
   __host__ __device__ int nit() const { return mp ? Lay<1>::NIT : Lay<0>::NIT; }
   __host__ __device__ int r_st() const { return 2 * nit(); }
   __host__ __device__ int nrows() const { return mp ? Lay<1>::NROWS : Lay<0>::NROWS; }
@@ -197,7 +197,7 @@ ASC_DEV void start_node(const Der &d, int K, int kk, int warm, bool probe, int f
 ASC_DEV void start_scal(const Der &d, int warm, bool probe, const double *zK, Scal &s) {
   if (!warm) s.th = 0.9;
   if (!probe) s.th = push_in(s.th, d.tlb, d.tub);
-  const Terminal tm = terminal_eval(d, zK);
+  const Terminal tm = terminal_of(d, zK);
   if (probe) {
   } else if (warm != 2) {
     s.s1 = fmax(tm.g1, 1e-2); s.s2 = fmax(tm.g2, 1e-2);
@@ -224,7 +224,7 @@ __global__ __launch_bounds__(WAVE) void p_init(const ascent_params *params, long
   const int k = blockIdx.x * WAVE + threadIdx.x, K = g.K, Kp = g.Kp;
   if (k >= Kp) return;
   double *w = ws + (size_t)p * g.nlp_doubles();
-  const Der d = derive(params[p]);
+  const Der d = derive_t(params[p], g.term);
   const int asked_warm = warm;
   if (warm && !(guess[(21L * K + S_TH) * batch + p] > 0.0)) warm = 0;
   const bool probe = probe_mu != nullptr;          // the iterate is taken as it is
@@ -273,7 +273,7 @@ __global__ __launch_bounds__(WAVE) void p_transfer(const ascent_params *params, 
   if (k >= Kpf) return;
   const double *wc = wsc + (size_t)p * gc.nlp_doubles(), *scc = wc + (size_t)gc.nrows() * Kpc;
   double *wf = wsf + (size_t)p * gf.nlp_doubles();
-  const Der d = derive(params[p]);
+  const Der d = derive_t(params[p], gf.term);
   const int warm = (int)scc[X_STATUS] == ASCENT_CONVERGED ? 2 : 0;
   const double *ic = wc + (size_t)((int)scc[X_CUR] * gc.nit()) * Kpc;
   double z[7], l[7], zb[6], u = 0.0, up = 0.0;
@@ -334,7 +334,7 @@ __global__ __launch_bounds__(WAVE * FIN_WAVES) void p_finish(const ascent_params
   const int c = blockIdx.x, K = g.K, Kp = g.Kp, nt = K + 1;
   const double *w = ws + (size_t)p * g.nlp_doubles();
   const double *sc = w + (size_t)g.nrows() * Kp;
-  const Der d = derive(params[p]);
+  const Der d = derive_t(params[p], g.term);
   const double *it = w + (size_t)((int)sc[X_CUR] * g.nit()) * Kp;
   if (c == 0 && threadIdx.y == 0) {
     const Scal s = lds_scal(sc, X_S);
@@ -413,7 +413,7 @@ __global__ __launch_bounds__(WAVE) void p_probe_rows_out(const ascent_params *pa
   const double *w = ws + (size_t)p * g.nlp_doubles();
   const double *sc = w + (size_t)g.nrows() * Kp, *rows = w + (size_t)g.r_st() * Kp;
   const double *it = w + (size_t)((int)sc[X_CUR] * g.nit()) * Kp;
-  const Der d = derive(params[p]);
+  const Der d = derive_t(params[p], g.term);
   const double a_ = it[(O_Z + IA) * Kp + k], m_ = it[(O_Z + IM) * Kp + k];
   const double siga = it[(O_ZB + 0) * Kp + k] * rcp(a_) + it[(O_ZB + 1) * Kp + k] * rcp(d.aub - a_);
   const double sigm = it[(O_ZB + 2) * Kp + k] * rcp(m_) + it[(O_ZB + 3) * Kp + k] * rcp(1.0 - m_);
@@ -488,7 +488,7 @@ struct TrialCtx {       // what the trial point of an NLP needs besides the node
 // the node's whole iterate and step (70).  Every accumulator of Part sees the same operations in the same order as in one pass.
 struct TrialKeep { double G[8], F[7], dza, dzm, zb4, zb5, zpp, zpn; };
 
-template <int SCHEME, int FORM, int MP = 0>
+template <int SCHEME, int FORM, int MP = 0, int TERM = 0>
 ASC_DEV void trial_primal(const Der &d, int K, int Kp, int k, const NodeIn &n, const NodeIn &dn, const TrialCtx &t, bool live,
                           double *in, Part &P, TrialKeep &kp) {
   const double alpha = t.alpha;
@@ -545,7 +545,7 @@ ASC_DEV void trial_primal(const Der &d, int K, int Kp, int k, const NodeIn &n, c
   }
   if (k == K - 1) {
     const Scal &stt = t.stt;
-    const Terminal tt = terminal_eval(d, z);
+    const Terminal tt = TERM == 2 ? terminal_eval_any(d, z) : terminal_eval(d, z);
     const double e1 = fabs(tt.e3), e2 = fabs(tt.g1 - stt.s1), e3 = fabs(tt.g2 - stt.s2);
     P.cinf = fmax(P.cinf, fmax(e1, fmax(e2, e3)));
     P.c1 += e1 + e2 + e3;
@@ -560,7 +560,7 @@ ASC_DEV void trial_primal(const Der &d, int K, int Kp, int k, const NodeIn &n, c
 }
 
 // ... and the rows with the trial multipliers l (node k), ln (node k+1), lu / lun (move penalty: of the movement equations)
-template <int SCHEME, int FORM, int MP = 0>
+template <int SCHEME, int FORM, int MP = 0, int TERM = 0>
 ASC_DEV void trial_dual(const Der &d, int K, int Kp, int k, const TrialKeep &kp, const double *l, const double *ln, double lu, double lun,
                         const TrialCtx &t, bool live, double *in, Part &P) {
   if (live) {
@@ -593,11 +593,18 @@ ASC_DEV void trial_dual(const Der &d, int K, int Kp, int k, const TrialKeep &kp,
     double z[7];
     ASC_UNROLL
     for (int i = 0; i < 7; i++) z[i] = in[(O_Z + i) * Kp + k];
-    const Terminal tt = terminal_eval(d, z);
-    r[IX] += stt.nu3 * tt.e3g[0] + stt.nu1 * tt.g1g[0];
-    r[IY] += stt.nu3 * tt.e3g[1] + stt.nu1 * tt.g1g[1];
-    r[IVX] += stt.nu3 * tt.e3g[2] + stt.nu2 * tt.g2g[0];
-    r[IVY] += stt.nu3 * tt.e3g[3] + stt.nu2 * tt.g2g[1];
+    if constexpr (TERM == 2) {
+      const Terminal tt = terminal_eval_any(d, z);
+      double g4[4];
+      terminal_grad_any(tt, stt.nu1, stt.nu2, g4);
+      r[IX] += g4[0]; r[IY] += g4[1]; r[IVX] += g4[2]; r[IVY] += g4[3];
+    } else {
+      const Terminal tt = terminal_eval(d, z);
+      r[IX] += stt.nu3 * tt.e3g[0] + stt.nu1 * tt.g1g[0];
+      r[IY] += stt.nu3 * tt.e3g[1] + stt.nu1 * tt.g1g[1];
+      r[IVX] += stt.nu3 * tt.e3g[2] + stt.nu2 * tt.g2g[0];
+      r[IVY] += stt.nu3 * tt.e3g[3] + stt.nu2 * tt.g2g[1];
+    }
   }
   ASC_UNROLL
   for (int i = 0; i < 7; i++) P.rd = fmax(P.rd, fabs(r[i]));
@@ -607,16 +614,16 @@ ASC_DEV void trial_dual(const Der &d, int K, int Kp, int k, const TrialKeep &kp,
 }
 
 // both parts in one go (line-search retries and the first point of a level)
-template <int SCHEME, int FORM, int MP = 0>
+template <int SCHEME, int FORM, int MP = 0, int TERM = 0>
 ASC_DEV void trial_node(const Der &d, int K, int Kp, int k, const NodeIn &n, const NodeIn &dn, const TrialCtx &t, bool live,
                         double *in, Part &P) {
   TrialKeep kp;
-  trial_primal<SCHEME, FORM, MP>(d, K, Kp, k, n, dn, t, live, in, P, kp);
+  trial_primal<SCHEME, FORM, MP, TERM>(d, K, Kp, k, n, dn, t, live, in, P, kp);
   double l[7], ln[7];
   ASC_UNROLL
   for (int i = 0; i < 7; i++) { l[i] = n.l[i] + t.alpha * dn.l[i]; ln[i] = n.ln[i] + t.alpha * dn.ln[i]; }
   const double lu = MP ? n.lu + t.alpha * dn.lu : 0.0, lun = MP ? n.lun + t.alpha * dn.lun : 0.0;
-  trial_dual<SCHEME, FORM, MP>(d, K, Kp, k, kp, l, ln, lu, lun, t, live, in, P);
+  trial_dual<SCHEME, FORM, MP, TERM>(d, K, Kp, k, kp, l, ln, lu, lun, t, live, in, P);
 }
 
 #ifdef PERSIST_PROFILE      // diagnostic build (scripts/persist_profile.py): shader cycles per phase, wavefront 0
@@ -629,7 +636,7 @@ ASC_DEV void trial_node(const Der &d, int K, int Kp, int k, const NodeIn &n, con
 #define PROF_END do { } while (0)
 #endif
 
-template <int SCHEME, int FORM, int MP = 0>
+template <int SCHEME, int FORM, int MP = 0, int TERM = 0>
 __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, long batch, PGeo g, double *ws, int max_iter, double tol) {
   using L = Lay<MP>;
   constexpr int NS = L::NS, NIT = L::NIT, R_ST = L::R_ST, R_KA = L::R_KA, R_K0 = L::R_K0, NROWS = L::NROWS;
@@ -650,7 +657,8 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
   double *w = ws + (size_t)pc * g.nlp_doubles();
   double *gsc = w + (size_t)NROWS * Kp;
   double *sc = lsc[grp];
-  const Der d = derive(params[pc]);
+  const Der d = TERM == 2 ? derive_t(params[pc], 2) : derive(params[pc]);      // (TERM = 2: burnout anywhere on the (r_peri, r_apo) ellipse)
+  static_assert(TERM == 0 || (TERM == 2 && FORM == 0), "terminal 2 is carried for the current formulation");
   for (int r = role; r < NSCAL; r += 16) sc[r] = gsc[r];
   if (role < 8) lds_d[grp][2][role] = 0.0;
   wsync();
@@ -692,7 +700,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             load_node<MP>(ic, Kp, K, k, n);
             if (first) dn = NodeIn{};             // (no step yet; the step rows are not initialised)
             else load_node<MP>(stp, Kp, K, k, dn);
-            trial_node<SCHEME, FORM, MP>(d, K, Kp, k, n, dn, t, live, in, P);
+            trial_node<SCHEME, FORM, MP, TERM>(d, K, Kp, k, n, dn, t, live, in, P);
           }
         }
         P.template reduce16<MP>();
@@ -811,7 +819,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
       double zK[7];
       ASC_UNROLL
       for (int i = 0; i < 7; i++) zK[i] = it[(O_Z + i) * Kp + K - 1];
-      const Terminal tm = terminal_eval(d, zK);
+      const Terminal tm = TERM == 2 ? terminal_eval_any(d, zK) : terminal_eval(d, zK);
       const double is1 = rcp(s.s1), is2 = rcp(s.s2);
       const double sig1 = s.zs1 * is1 + dw, sig2 = s.zs2 * is2 + dw;
       const double rs1 = -mu * is1 - s.nu1, rs2 = -mu * is2 - s.nu2;
@@ -820,10 +828,12 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
         double Qt[28];
         ASC_UNROLL
         for (int i = 0; i < 28; i++) Qt[i] = 0.0;
-        terminal_hessian(Qt, tm, s.nu3, s.nu1, s.nu2, sig1, sig2);
+        if constexpr (TERM == 2) terminal_hessian_any(Qt, tm, s.nu1, s.nu2, sig1, sig2);
+        else terminal_hessian(Qt, tm, s.nu3, s.nu1, s.nu2, sig1, sig2);
         const double w1 = s.nu1 + sig1 * cg1 + rs1, w2 = s.nu2 + sig2 * cg2 + rs2;
-        const double r0[4] = {s.nu3 * tm.e3g[0] + w1 * tm.g1g[0], s.nu3 * tm.e3g[1] + w1 * tm.g1g[1],
-                              s.nu3 * tm.e3g[2] + w2 * tm.g2g[0], s.nu3 * tm.e3g[3] + w2 * tm.g2g[1]};
+        double r0[4] = {s.nu3 * tm.e3g[0] + w1 * tm.g1g[0], s.nu3 * tm.e3g[1] + w1 * tm.g1g[1],
+                        s.nu3 * tm.e3g[2] + w2 * tm.g2g[0], s.nu3 * tm.e3g[3] + w2 * tm.g2g[1]};
+        if constexpr (TERM == 2) terminal_grad_any(tm, w1, w2, r0);
         ASC_UNROLL
         for (int i = 0; i < 7; i++) {
           double v = 0.0;
@@ -1060,7 +1070,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
           const double itl = rcp(s.th - d.tlb), itu = rcp(d.tub - s.th);
           const double rthp = sc[X_RTH] + mu * (itu - itl);
           const double sth = s.zlt * itl + s.zut * itu + dw;
-          const double a11 = sth - S11, a12 = -S12, a22 = -S22;
+          const double a11 = sth - S11, a12 = -S12, a22 = TERM == 2 ? -1.0 : -S22;      // (TERM 2: no r.v = 0 row; a unit pivot closes nu3)
           const double b1 = -rthp + S10, b2 = -tm.e3 + S20;
           const double det = a11 * a22 - a12 * a12;
           if (det < 0.0) {
@@ -1335,11 +1345,15 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
         double zK[7];
         ASC_UNROLL
         for (int i = 0; i < 7; i++) zK[i] = it[(O_Z + i) * Kp + K - 1];
-        const Terminal tmK = terminal_eval(d, zK);
+        const Terminal tmK = TERM == 2 ? terminal_eval_any(d, zK) : terminal_eval(d, zK);
         Scal ds;
         ds.th = dth; ds.nu3 = dnu3;
         ds.s1 = sc[X_CG1] + tmK.g1g[0] * dzK[IX] + tmK.g1g[1] * dzK[IY];
         ds.s2 = sc[X_CG2] + tmK.g2g[0] * dzK[IVX] + tmK.g2g[1] * dzK[IVY];
+        if constexpr (TERM == 2) {
+          ds.s1 += tmK.g1v[0] * dzK[IVX] + tmK.g1v[1] * dzK[IVY];
+          ds.s2 += tmK.g2p[0] * dzK[IX] + tmK.g2p[1] * dzK[IY];
+        }
         ds.nu1 = sig1 * ds.s1 + rs1;
         ds.nu2 = sig2 * ds.s2 + rs2;
         ds.zs1 = mu / s.s1 - s.zs1 - s.zs1 / s.s1 * ds.s1;
@@ -1421,18 +1435,25 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             r[IM] -= H[3] * dz[IX] + H[6] * dz[IY] + H[8] * dz[IA] + H[9] * dz[IM];
             if (kn == K - 1) {
               double QT[28], qd[7];
-              const Terminal tm = terminal_eval(d, n.z);
+              const Terminal tm = TERM == 2 ? terminal_eval_any(d, n.z) : terminal_eval(d, n.z);
               ASC_UNROLL
               for (int i = 0; i < 28; i++) QT[i] = 0.0;
-              terminal_hessian(QT, tm, s.nu3, s.nu1, s.nu2, sig1, sig2);
+              if constexpr (TERM == 2) terminal_hessian_any(QT, tm, s.nu1, s.nu2, sig1, sig2);
+              else terminal_hessian(QT, tm, s.nu3, s.nu1, s.nu2, sig1, sig2);
               symv(QT, dz, qd);
               ASC_UNROLL
               for (int i = 0; i < 7; i++) r[i] -= qd[i];
               const double w1 = s.nu1 + sig1 * sc[X_CG1] + rs1, w2 = s.nu2 + sig2 * sc[X_CG2] + rs2;
+              if constexpr (TERM == 2) {
+                double g4[4];
+                terminal_grad_any(tm, w1, w2, g4);
+                r[IX] -= g4[0]; r[IY] -= g4[1]; r[IVX] -= g4[2]; r[IVY] -= g4[3];
+              } else {
               r[IX] -= s.nu3 * tm.e3g[0] + w1 * tm.g1g[0] + tm.e3g[0] * dnu3;
               r[IY] -= s.nu3 * tm.e3g[1] + w1 * tm.g1g[1] + tm.e3g[1] * dnu3;
               r[IVX] -= s.nu3 * tm.e3g[2] + w2 * tm.g2g[0] + tm.e3g[2] * dnu3;
               r[IVY] -= s.nu3 * tm.e3g[3] + w2 * tm.g2g[1] + tm.e3g[3] * dnu3;
+              }
             }
             double wv[7];
             solveAT<FORM>(G, E, cs, r, wv);
@@ -1461,7 +1482,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             ASC_UNROLL
             for (int i = 0; i < 7; i++) stage[(6 * i + 5) * LDW + col] = wv[i];
             // the primal step of the chunk is known: the primal part of its trial point at the first step length, before the sweep
-            trial_primal<SCHEME, FORM, MP>(d, K, Kp, kn, n, dn, tc, live, in, P, kp);
+            trial_primal<SCHEME, FORM, MP, TERM>(d, K, Kp, kn, n, dn, tc, live, in, P, kp);
           }
           wsync();
           PROF(7);
@@ -1510,7 +1531,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
               lu = it[O_LU * Kp + kn] + tc.alpha * stp[O_LU * Kp + kn];
               lun = (kn + 1 < K ? it[O_LU * Kp + kn + 1] : 0.0) + tc.alpha * (kn + 1 < K ? stp[O_LU * Kp + kn + 1] : 0.0);
             }
-            trial_dual<SCHEME, FORM, MP>(d, K, Kp, kn, kp, l, ln, lu, lun, tc, live, in, P);
+            trial_dual<SCHEME, FORM, MP, TERM>(d, K, Kp, kn, kp, l, ln, lu, lun, tc, live, in, P);
           }
           PROF(0);
         }
@@ -1559,9 +1580,9 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
 
 namespace ascent {
 
-static PGeo geo_of(int K, int form = 0, int mp = 0) {
+static PGeo geo_of(int K, int form = 0, int mp = 0, int term = 0) {
   PGeo g;
-  g.K = K; g.nch = (K + CH - 1) / CH; g.Kp = g.nch * CH; g.form = form; g.mp = mp ? 1 : 0;
+  g.K = K; g.nch = (K + CH - 1) / CH; g.Kp = g.nch * CH; g.form = form; g.mp = mp ? 1 : 0; g.term = term == 2 ? 2 : 0;
   return g;
 }
 
@@ -1584,6 +1605,13 @@ size_t persist_ws_bytes_nested(const int *levels, int nlev, long batch, int mp) 
 static void launch_solve(int scheme, int form, int mp, long batch, hipStream_t stream, const ascent_params *dp, const PGeo &g, double *w,
                          int max_iter, double tol) {
   const dim3 grid((unsigned)((batch + NPW - 1) / NPW)), block(WAVE);
+  if (g.term == 2) {      // burnout anywhere on the ellipse (formulation 0)
+    if (mp && scheme == 1) hipLaunchKernelGGL((p_solve<1, 0, 1, 2>), grid, block, 0, stream, dp, batch, g, w, max_iter, tol);
+    else if (mp) hipLaunchKernelGGL((p_solve<0, 0, 1, 2>), grid, block, 0, stream, dp, batch, g, w, max_iter, tol);
+    else if (scheme == 1) hipLaunchKernelGGL((p_solve<1, 0, 0, 2>), grid, block, 0, stream, dp, batch, g, w, max_iter, tol);
+    else hipLaunchKernelGGL((p_solve<0, 0, 0, 2>), grid, block, 0, stream, dp, batch, g, w, max_iter, tol);
+    return;
+  }
   if (mp && scheme == 1) hipLaunchKernelGGL((p_solve<1, 0, 1>), grid, block, 0, stream, dp, batch, g, w, max_iter, tol);
   else if (mp) hipLaunchKernelGGL((p_solve<0, 0, 1>), grid, block, 0, stream, dp, batch, g, w, max_iter, tol);
   else if (scheme == 1) hipLaunchKernelGGL((p_solve<1, 0, 0>), grid, block, 0, stream, dp, batch, g, w, max_iter, tol);
@@ -1594,19 +1622,19 @@ static void launch_solve(int scheme, int form, int mp, long batch, hipStream_t s
 // All grid levels of the nested iteration (levels[0] = the requested grid, finest first; the coarsest is solved first, cold or
 // from the caller's guess): p_init, then per level p_solve and p_transfer to the next finer grid, p_finish at the end.  Two
 // workspace regions alternate between the levels.  mp: with the l1 move penalty (schemes 0 / 1, formulation 0).
-int persist_run_nested(const ascent_params *dp, long batch, int scheme, int form, int mp, const int *levels, int nlev, double *ws, const double *dguess, int warm,
+int persist_run_nested(const ascent_params *dp, long batch, int scheme, int form, int mp, int term, const int *levels, int nlev, double *ws, const double *dguess, int warm,
                        int max_iter, double tol, double tol_coarse, double mu0, double mu_first, double mu_next, double *dtraj,
                        double *dtf, int *dstatus, int *diters, double *dblob, hipStream_t stream, char *err, size_t errlen) {
-  if (mp && form != 0) { snprintf(err, errlen, "the persistent kernel carries the move penalty for formulation 0 only"); return ASCENT_E_ARG; }
+  if ((mp || term == 2) && form != 0) { snprintf(err, errlen, "the persistent kernel carries the move penalty and terminal 2 for formulation 0 only"); return ASCENT_E_ARG; }
   double *region[2] = {ws, (double *)((char *)ws + persist_region1_offset(levels, batch, mp))};
-  PGeo g = geo_of(levels[nlev - 1] - 1, form, mp);
+  PGeo g = geo_of(levels[nlev - 1] - 1, form, mp, term);
   double *w = region[(nlev - 1) & 1];
   hipLaunchKernelGGL(p_init, dim3((unsigned)((g.Kp + WAVE - 1) / WAVE), (unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g, w, dguess,
                      warm, mu0, (const double *)nullptr, (const double *)nullptr, 0);
   for (int l = nlev - 1; l >= 0; l--) {
     launch_solve(scheme, form, mp, batch, stream, dp, g, w, max_iter, l == 0 ? tol : tol_coarse);
     if (l > 0) {
-      const PGeo gf = geo_of(levels[l - 1] - 1, form, mp);
+      const PGeo gf = geo_of(levels[l - 1] - 1, form, mp, term);
       double *wf = region[(l - 1) & 1];
       hipLaunchKernelGGL(p_transfer, dim3((unsigned)((gf.Kp + WAVE - 1) / WAVE), (unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g,
                          (const double *)w, gf, wf, l == nlev - 1 ? mu_first : mu_next);
@@ -1622,10 +1650,10 @@ int persist_run_nested(const ascent_params *dp, long batch, int scheme, int form
 // One round of p_solve at a caller-supplied iterate (parity surface ascent_kkt_step_path): the iterate as it is, mu and
 // delta_w per problem from the caller; p_probe_out hands back the Newton step.  (mp: the slack pairs, which the blob does
 // not carry, are set around the iterate's own movement as every warm start sets them.)
-int persist_probe(const ascent_params *dp, long batch, int scheme, int form, int mp, int K, double *ws, const double *diterate, const double *dmu, const double *ddw,
+int persist_probe(const ascent_params *dp, long batch, int scheme, int form, int mp, int term, int K, double *ws, const double *diterate, const double *dmu, const double *ddw,
                   double *dstep, int *dinertia, hipStream_t stream, char *err, size_t errlen) {
-  if (mp && form != 0) { snprintf(err, errlen, "the persistent kernel carries the move penalty for formulation 0 only"); return ASCENT_E_ARG; }
-  const PGeo g = geo_of(K, form, mp);
+  if ((mp || term == 2) && form != 0) { snprintf(err, errlen, "the persistent kernel carries the move penalty and terminal 2 for formulation 0 only"); return ASCENT_E_ARG; }
+  const PGeo g = geo_of(K, form, mp, term);
   const dim3 ng((unsigned)((g.Kp + WAVE - 1) / WAVE), (unsigned)batch);
   hipLaunchKernelGGL(p_init, ng, dim3(WAVE), 0, stream, dp, batch, g, ws, diterate, 2, 0.1, dmu, ddw, 1);
   launch_solve(scheme, form, mp, batch, stream, dp, g, ws, 1000, -1.0);

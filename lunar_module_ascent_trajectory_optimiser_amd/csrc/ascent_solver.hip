@@ -924,10 +924,10 @@ __global__ __launch_bounds__(WAVE) void k_terminal_params(const ascent_params *i
 }
 
 bool use_dense_path(const ascent_opts *o, int64_t batch) {
-  if (o->scheme == 2 || o->solver_path == ASCENT_PATH_DENSE || o->terminal == 2) return true;
+  if (o->scheme == 2 || o->solver_path == ASCENT_PATH_DENSE) return true;
   const char *e = getenv("ASCENT_PIPELINE");
-  // (the move penalty exists in the persistent kernel and in the dense-block path: an override that names any other family means the dense one)
-  if (o->move_penalty && ((e && strcmp(e, "persist")) || getenv("ASCENT_FACTOR"))) return true;
+  // (the move penalty and terminal 2 exist in the persistent kernel and in the dense-block path: an override that names any other family means the dense one)
+  if ((o->move_penalty || o->terminal == 2) && ((e && strcmp(e, "persist")) || getenv("ASCENT_FACTOR"))) return true;
   if (e) return !strcmp(e, "dense") && o->formulation == 0;
   // A handful of NLPs cannot fill the hand-tuned kernels (one wavefront per four NLPs, serial over the nodes: 2.8 ms at
   // N=200, 7.3 ms at N=600, 25-31 ms at N=2000 for up to 8 NLPs); the dense-block path with its Newton systems solved by
@@ -1080,7 +1080,7 @@ int check_common(const ascent_params *p, int64_t batch, const ascent_opts *o, in
   if (o->coarse_nodes != -1 && o->coarse_nodes != 0 && (o->coarse_nodes < 3 || o->coarse_nodes >= o->n_nodes)) { snprintf(g_err, sizeof g_err, "coarse_nodes must be -1 (off), 0 (automatic) or in [3, n_nodes)"); return ASCENT_E_ARG; }
   if (o->scheme < 0 || o->scheme > 2) { snprintf(g_err, sizeof g_err, "scheme %d not supported (0 = backward Euler, the reference's NODES=2; 1 = trapezoid; 2 = Hermite-Simpson)", o->scheme); return ASCENT_E_ARG; }
   if (o->terminal < 0 || o->terminal > 2) { snprintf(g_err, sizeof g_err, "terminal %d not supported (0 = reference, 1 = periapsis of the ellipse, 2 = anywhere on the ellipse)", o->terminal); return ASCENT_E_ARG; }
-  if (o->terminal == 2 && o->formulation != 0) { snprintf(g_err, sizeof g_err, "terminal 2 (the dense-block path) has formulation 0 only"); return ASCENT_E_ARG; }
+  if (o->terminal == 2 && o->formulation != 0) { snprintf(g_err, sizeof g_err, "terminal 2 has formulation 0 only"); return ASCENT_E_ARG; }
   if (o->solver_path != ASCENT_PATH_AUTO && o->solver_path != ASCENT_PATH_DENSE) { snprintf(g_err, sizeof g_err, "solver_path must be 0 (automatic) or ASCENT_PATH_DENSE"); return ASCENT_E_ARG; }
   if ((o->scheme == 2 || o->solver_path == ASCENT_PATH_DENSE) && o->formulation != 0) { snprintf(g_err, sizeof g_err, "the dense-block path (scheme 2 / ASCENT_PATH_DENSE) has formulation 0 only"); return ASCENT_E_ARG; }
   if (o->move_penalty && o->formulation != 0) { snprintf(g_err, sizeof g_err, "move_penalty = 1 is carried for formulation 0 only"); return ASCENT_E_ARG; }
@@ -1237,7 +1237,7 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
   double mu_first = NESTED_MU_FIRST, mu_next = nested_mu_next(o->tol);
   if (const char *e = getenv("ASCENT_NESTED_MU")) sscanf(e, "%lf,%lf", &mu_first, &mu_next);      // experiments only ("first,next")
   if (persist) {      // all levels inside the kernel's own layout
-    rc = persist_run_nested(dp, (long)batch, (int)o->scheme, (int)o->formulation, (int)o->move_penalty, levels, nlev, w.ws, dguess, (int)o->warm_start, (int)o->max_iter, o->tol,
+    rc = persist_run_nested(dp, (long)batch, (int)o->scheme, (int)o->formulation, (int)o->move_penalty, o->terminal == 2 ? 2 : 0, levels, nlev, w.ws, dguess, (int)o->warm_start, (int)o->max_iter, o->tol,
                             fmax(o->tol, NESTED_COARSE_TOL), mu0, mu_first, mu_next, dtraj, dtf, dstatus, diters,
                             dblob, stream, g_err, sizeof g_err);
     if (rc) return rc;
@@ -1396,7 +1396,7 @@ int ascent_kkt_step_path(const ascent_params *p, int64_t batch, const ascent_opt
   const size_t rows = 21 * (size_t)K + NSC;
   const int lpt = lanes_per_tile(batch);
   const bool pcr_probe = path == ASCENT_PATH_DENSE && o->terminal != 2 && use_pcr_newton(batch, o->move_penalty != 0);
-  if (o->terminal == 2 && path != ASCENT_PATH_DENSE) { snprintf(g_err, sizeof g_err, "terminal 2 exists in the dense-block path only"); return ASCENT_E_ARG; }
+  if (o->terminal == 2 && path != ASCENT_PATH_DENSE && path != ASCENT_PATH_PERSIST) { snprintf(g_err, sizeof g_err, "terminal 2 exists in the persistent kernel and in the dense-block path only"); return ASCENT_E_ARG; }
   rc = ensure_ws(g_ws_slot0(device_id), path == ASCENT_PATH_DENSE ? (pcr_probe ? dense_pcr_ws_bytes(K, (long)batch) : dense_ws_bytes(K, (long)batch))
                             : path == ASCENT_PATH_PERSIST ? persist_ws_bytes(K, (long)batch, (int)o->move_penalty) : path == ASCENT_PATH_FUSED ? ws_bytes(K, batch, lpt) : pipeline_ws_bytes(K, (long)batch));
   if (rc) return rc;
@@ -1419,7 +1419,7 @@ int ascent_kkt_step_path(const ascent_params *p, int64_t batch, const ascent_opt
                      0, g_err, sizeof g_err, pcr_probe ? 1 : 0, (int)o->move_penalty);
     if (rc) return rc;
   } else if (path == ASCENT_PATH_PERSIST) {
-    rc = persist_probe(bp.d, (long)batch, (int)o->scheme, (int)o->formulation, (int)o->move_penalty, K, g_ws_slot0(device_id).ws, bit.d, bmu.d, bdw.d, bst.d, bin.d, 0, g_err, sizeof g_err);
+    rc = persist_probe(bp.d, (long)batch, (int)o->scheme, (int)o->formulation, (int)o->move_penalty, o->terminal == 2 ? 2 : 0, K, g_ws_slot0(device_id).ws, bit.d, bmu.d, bdw.d, bst.d, bin.d, 0, g_err, sizeof g_err);
     if (rc) return rc;
   } else if (path == ASCENT_PATH_FUSED) {
     hipLaunchKernelGGL(k_kkt_step, dim3((unsigned)((batch + lpt - 1) / lpt)), dim3(WAVE), 0, 0, bp.d, (long)batch, lpt, K,

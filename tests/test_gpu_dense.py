@@ -236,10 +236,13 @@ def test_terminal2_burnout_anywhere_on_the_ellipse_then_coast():
     assert n >= 3
     assert A.default_path(16, 200, scheme=0) == "persist"
     S = A.sweep_isp_drymass(4, 4)
-    for scheme in (0, 2):
+    for scheme in (0, 1, 2):      # schemes 0 / 1: the persistent kernel (p_solve<.,0,.,2>), scheme 2: the dense-block path
         r1 = A.solve_batch(S, 200, tol=1e-9, scheme=scheme, terminal="ellipse", max_iter=500)
         r2 = A.solve_batch(S, 200, tol=1e-9, scheme=scheme, terminal="ellipse_free", max_iter=500)
         assert np.all(r1.status == 0) and np.all(r2.status == 0)
+        if scheme < 2:            # ... against the dense-block path: two independent HIP implementations of the terminal block
+            rd = A.solve_batch(S, 200, tol=1e-9, scheme=scheme, terminal="ellipse_free", max_iter=500, path="dense")
+            assert np.all(rd.status == 0) and np.abs(rd.tf - r2.tf).max() <= 1e-9
         o = r2.orbit()
         assert np.abs(o["periapsis_alt"] - 17703.0).max() < 1.0 and np.abs(o["apoapsis_alt"] - 88615.0).max() < 1.0
         assert np.all(r2.tf <= r1.tf + 1e-12) and np.all(r1.tf - r2.tf < 1e-4)

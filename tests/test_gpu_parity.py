@@ -198,6 +198,27 @@ def test_move_penalty_in_the_persistent_kernel_matches_the_oracle_on_a_sweep(cor
     assert np.all(warm.status == 0) and warm.iters.max() <= 12 and np.abs(warm.tf - full.tf).max() <= 1e-8
 
 
+@pytest.mark.parametrize("scheme,mp", [(0, False), (1, False), (0, True)])
+def test_kkt_step_with_terminal2_persistent_kernel_equals_dense_path(coracle, monkeypatch, scheme, mp):
+    """ascent_opts.terminal = 2 (burnout anywhere on the ellipse) at step level: one Newton step through one round of
+    p_solve<.,0,.,2> against the dense-block path's Riccati form -- two independent HIP implementations of the generalised terminal
+    block (gradients of both conditions in position AND velocity, the antisymmetric position-velocity Hessian of the angular
+    momentum, the unit pivot that closes the absent r.v = 0 row) -- with and without regularisation and the move penalty."""
+    monkeypatch.setenv("ASCENT_DENSE_NEWTON", "riccati")
+    nt = 60
+    S = A.sweep_isp_drymass(2, 3)
+    S[:, 15] = 1e-5
+    blobs = _interior_blobs(coracle, S, nt, scheme, 0)
+    mu = np.array([0.1, 0.02, 1e-3, 0.05, 1e-6, 0.2]); dw = np.array([0.0, 1e-3, 1e-2, 1.0, 0.0, 1e-4])
+    sp, ip = A.kkt_step(S, blobs, mu, dw, nt, path="persist", scheme=scheme, terminal=2, move_penalty=mp)
+    sd, idn = A.kkt_step(S, blobs, mu, dw, nt, path="dense", scheme=scheme, terminal=2, move_penalty=mp)
+    s0, _ = A.kkt_step(S, blobs, mu, dw, nt, path="persist", scheme=scheme, terminal=1, move_penalty=mp)
+    assert np.array_equal(ip, idn) and (ip == 0).sum() >= 3
+    for b in np.flatnonzero(ip == 0):
+        assert np.abs(sp[:, b] - sd[:, b]).max() <= 1e-9 * max(1.0, np.abs(sd[:, b]).max())
+        assert np.abs(sp[:, b] - s0[:, b]).max() > 1e-6          # (another terminal block: another step)
+
+
 @pytest.mark.parametrize("path", ["fused", "split_lane", "split_wide", "persist"])
 def test_kkt_step_detects_wrong_inertia(coracle, path):
     """A strongly negative curvature (flipped multipliers) must be reported, not solved through."""
