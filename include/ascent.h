@@ -66,7 +66,8 @@ typedef struct ascent_opts {
                            0 = automatic (grids of >= 40 nodes; coarse grid = max(14, (3 n_nodes + 5)/10) nodes,
                            recursively: 201 -> 60 -> 17 -- a grid one to three intervals beyond a multiple of 16 gives them up; coarse levels are solved to max(tol, 1e-3); a level
                            warm-started from the cold-started coarsest grid begins at mu = 1e-6, one warm-started
-                           from a warm-started grid at mu = max(1e-9, tol/100)), -1 = off (single grid),
+                           from a warm-started grid at mu = max(1e-9, tol/100); with move_penalty = 1: 1e-5 and
+                           max(1e-8, 10 tol)), -1 = off (single grid),
                            > 0 = that many coarse nodes (two levels).
                            iters_out counts the iterations of all levels.                              */
   int32_t terminal;     /* 0 = the reference's terminal speed (:72-78: circular speed of the MEAN radius, imposed at

@@ -853,6 +853,11 @@ int hip_fail(hipError_t e, const char *what) {
 constexpr int NESTED_MIN_NODES = 40;
 constexpr double NESTED_MU_FIRST = 1e-6;     // warm start from the cold-started coarsest grid
 inline double nested_mu_next(double tol) { return fmax(1e-9, 1e-2 * tol); }      // warm start from a grid that was warm-started itself (tol: of the finest grid)
+// ... with the move penalty: the slack pairs of the movement equations are re-centred on every grid, and where the control's movement
+// changes sign a pair swaps roles through the kink of |.| -- at mu = 1e-9 up to seven fraction-to-boundary-limited iterations; started
+// at 1e-5 / 1e-8 the config-3 sweep's 200-node level takes 9-13 iterations instead of 9-16 (the kernel waits for its slowest NLP)
+constexpr double NESTED_MU_FIRST_MP = 1e-5;
+inline double nested_mu_next_mp(double tol) { return fmax(1e-8, 10.0 * tol); }
 constexpr double NESTED_COARSE_TOL = 1e-3;   // coarse levels: the reference's own OTOL/RTOL (their discretisation error is 1e-2)
 // (three tenths of the nodes; a grid that would spill one to three intervals into another 16-interval chunk of the
 //  persistent kernel gives them up: 18 nodes -> 17)
@@ -1234,7 +1239,7 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
     w.int_n = n3;
   }
   HIPCHK(hipEventRecord(w.ev0, stream));
-  double mu_first = NESTED_MU_FIRST, mu_next = nested_mu_next(o->tol);
+  double mu_first = o->move_penalty ? NESTED_MU_FIRST_MP : NESTED_MU_FIRST, mu_next = o->move_penalty ? nested_mu_next_mp(o->tol) : nested_mu_next(o->tol);
   if (const char *e = getenv("ASCENT_NESTED_MU")) sscanf(e, "%lf,%lf", &mu_first, &mu_next);      // experiments only ("first,next")
   if (persist) {      // all levels inside the kernel's own layout
     rc = persist_run_nested(dp, (long)batch, (int)o->scheme, (int)o->formulation, (int)o->move_penalty, o->terminal == 2 ? 2 : 0, levels, nlev, w.ws, dguess, (int)o->warm_start, (int)o->max_iter, o->tol,

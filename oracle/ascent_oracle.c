@@ -956,6 +956,13 @@ static int coarse_of(int nt) {      /* one to three intervals beyond a multiple 
 #define NESTED_MIN_NODES 40
 #define NESTED_MU_FIRST 1e-6
 #define NESTED_MU_NEXT(tol_finest) fmax(1e-9, 1e-2 * (tol_finest))
+/* ... with the move penalty: 1e-5 and max(1e-8, 10 tol).  The slack pairs of the movement equations are re-centred on every grid
+ * (solve_one), and wherever the control's movement changes sign between the prolonged guess and the grid's own solution a pair
+ * has to swap roles through the kink of |.|: at a barrier parameter of 1e-9 that costs the affected problems up to seven
+ * fraction-to-boundary-limited iterations (config-3 sweep, 200-node grid: 9-16 iterations, mean 10.9; with these starts 9-13,
+ * mean 10.5, and 3-4 instead of 4-5 on the 60-node grid; the unpenalised problem is best left at 1e-6 / 1e-9). */
+#define NESTED_MU_FIRST_MP 1e-5
+#define NESTED_MU_NEXT_MP(tol_finest) fmax(1e-8, 10.0 * (tol_finest))
 #define NESTED_COARSE_TOL 1e-3    /* the coarse levels are solved to the reference's own OTOL/RTOL, not to `tol` */
 
 static void prolong(const double *bc, int Kc, double *bf, int Kf) {
@@ -994,7 +1001,8 @@ static int solve_nested(const oparams *prm, int nt, int max_iter, double tol, do
   int warm = 0;
   if (stc == ST_CONVERGED) { prolong(bc, nc - 1, blob, nt - 1); warm = 2; }
   free(bc);
-  const int st = solve_one(prm, nt, max_iter, tol, warm, depth_c == 0 ? NESTED_MU_FIRST : NESTED_MU_NEXT(tol_finest), blob, &itf, 0);
+  const double mu_first = g_mp ? NESTED_MU_FIRST_MP : NESTED_MU_FIRST, mu_next = g_mp ? NESTED_MU_NEXT_MP(tol_finest) : NESTED_MU_NEXT(tol_finest);
+  const int st = solve_one(prm, nt, max_iter, tol, warm, depth_c == 0 ? mu_first : mu_next, blob, &itf, 0);
   *iters_out = itc + itf;
   if (depth_out) *depth_out = depth_c + 1;
   return st;

@@ -393,7 +393,7 @@ def test_move_penalty_batch_and_dispatch():
             rr = A.solve_batch(S, 100, tol=1e-9, move_penalty=True, max_iter=500, path="dense")
         finally:
             del os.environ["ASCENT_DENSE_NEWTON"]
-        assert np.all(rr.status == 0) and np.abs(rr.tf - on.tf).max() <= 2e-9 and np.abs(rr.iters.astype(int) - on.iters).max() <= 4
+        assert np.all(rr.status == 0) and np.abs(rr.tf - on.tf).max() <= 2e-8 and np.abs(rr.iters.astype(int) - on.iters).max() <= 4
     # nine orders of magnitude of the weight in one batch: all converge, t_f and the total variation are monotone in it,
     # and the rise of t_f is bounded by the penalty the unpenalised control would pay
     W = np.array([1e-9, 1e-7, 1e-5, 1e-3, 1e-1, 1.0])

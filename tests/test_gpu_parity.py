@@ -186,7 +186,7 @@ def test_move_penalty_in_the_persistent_kernel_matches_the_oracle_on_a_sweep(cor
         assert np.abs(r.tf - ref["tf"]).max() <= 1e-12
         assert np.abs(np.moveaxis(r.traj, 2, 0)[:, :8] - ref["traj"][:, :8]).max() < 1e-6
         dn = A.solve_batch(S[::5], NT, tol=1e-9, scheme=scheme, move_penalty=True, path="dense")
-        assert np.all(dn.status == 0) and np.abs(dn.tf - r.tf[::5]).max() <= 5e-9     # (<= 32 NLPs: its PCR variant, another regularisation rule)
+        assert np.all(dn.status == 0) and np.abs(dn.tf - r.tf[::5]).max() <= 2e-8     # (<= 32 NLPs: its PCR variant, another regularisation rule; two KKT points at tol 1e-9)
     # ragged batch, dead wavefront groups, an odd grid, an iteration cap, warm start from the penalised solution
     r5 = A.solve_batch(S[:5], 37, tol=1e-9, move_penalty=True)
     o5 = coracle.solve_batch(S[:5], 37, 300, 1e-9, move_penalty=True)
