@@ -239,10 +239,11 @@ __global__ __launch_bounds__(WAVE) void p_init(const ascent_params *params, long
   }
   start_node(d, K, kk, warm, probe, g.form, z, l, zb, u);
   store_start(w, Kp, k, z, l, zb, u);
-  if (g.mp) {
-    double up = (kk > 0 && warm) ? guess[(7L * K + kk - 1) * batch + p] : 0.0;
+  if (g.mp) {       // (v1: the MV is the angle = (aub/2)(u + 1), starts at 0 and carries DCOST itself)
+    const double ha = 0.5 * d.aub, f0 = (double)kk / K * 0.5;             // (cold start: the straight-line guess of node kk-1)
+    double up = kk == 0 ? (g.form == 1 ? -1.0 : 0.0) : warm ? guess[(7L * K + kk - 1) * batch + p] : (g.form == 1 ? f0 / ha - 1.0 : 0.0);
     if (kk > 0 && !probe) up = push_in(up, -1.0, 1.0);
-    start_move(w, Kp, k, u, up, warm != 0, params[p].dcost);
+    start_move(w, Kp, k, u, up, warm != 0, g.form == 1 ? params[p].dcost * ha : params[p].dcost);
   }
   if (k != K - 1) return;
   double *sc = w + (size_t)g.nrows() * Kp;
@@ -310,7 +311,11 @@ __global__ __launch_bounds__(WAVE) void p_transfer(const ascent_params *params, 
   }
   start_node(d, Kf, kk, warm, false, gf.form, z, l, zb, u);
   store_start(wf, Kpf, k, z, l, zb, u);
-  if (gf.mp) start_move(wf, Kpf, k, u, up, warm != 0, params[p].dcost);
+  if (gf.mp) {
+    if (kk == 0) up = gf.form == 1 ? -1.0 : 0.0;
+    else if (!warm && gf.form == 1) up = push_in((double)kk / Kf * 0.5 / (0.5 * d.aub) - 1.0, -1.0, 1.0);      // (cold: the guess of node kk-1)
+    start_move(wf, Kpf, k, u, up, warm != 0, gf.form == 1 ? params[p].dcost * 0.5 * d.aub : params[p].dcost);
+  }
   if (k != Kf - 1) return;
   double *sc = wf + (size_t)gf.nrows() * Kpf;
   Scal s;
@@ -432,8 +437,10 @@ struct NodeIn {      // what a node evaluation reads: node k of the iterate, the
   double z[7], zp[7], l[7], ln[7], zb[6], u;
   double up, lu, lun, pp, pn, zpp, zpn;      // move penalty only: u_{k-1}, lambda_u of nodes k and k+1, the slack pair and its multipliers
 };
+// (uinit: the control "before node 0" of the movement equations -- the MV's initial value: 0, or -1 where the v1 formulation's
+//  angle starts at 0; loads of a STEP pass 0)
 template <int MP = 0>
-ASC_DEV void load_node(const double *it, int Kp, int K, int k, NodeIn &n) {
+ASC_DEV void load_node(const double *it, int Kp, int K, int k, NodeIn &n, double uinit = 0.0) {
   ASC_UNROLL
   for (int i = 0; i < 7; i++) {
     n.z[i] = it[(O_Z + i) * Kp + k];
@@ -445,7 +452,7 @@ ASC_DEV void load_node(const double *it, int Kp, int K, int k, NodeIn &n) {
   ASC_UNROLL
   for (int b = 0; b < 6; b++) n.zb[b] = it[(O_ZB + b) * Kp + k];
   if constexpr (MP) {
-    n.up = k > 0 ? it[O_U * Kp + k - 1] : 0.0;
+    n.up = k > 0 ? it[O_U * Kp + k - 1] : uinit;
     n.lu = it[O_LU * Kp + k];
     n.lun = k + 1 < K ? it[O_LU * Kp + k + 1] : 0.0;
     n.pp = it[O_PP * Kp + k]; n.pn = it[O_PN * Kp + k]; n.zpp = it[O_ZP * Kp + k]; n.zpn = it[O_ZN * Kp + k];
@@ -642,7 +649,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
   constexpr int NS = L::NS, NIT = L::NIT, R_ST = L::R_ST, R_KA = L::R_KA, R_K0 = L::R_K0, NROWS = L::NROWS;
   constexpr int S_G = L::S_G, S_E = L::S_E, S_H = L::S_H, S_F = L::S_F, S_C = L::S_C, S_RZ = L::S_RZ, S_GT = L::S_GT, S_SC = L::S_SC;
   constexpr int RL = NS;                                // the first of the three right-hand-side lanes of the factorisation sweep
-  static_assert(FORM == 0 || MP == 0, "the move penalty is carried for the current formulation only");
+  static_assert(FORM == 0 || SCHEME == 0, "the v1 formulation is restated with backward Euler");
   __shared__ double stage[L::S_ROWS * LDW];
   __shared__ double outb[L::OUT_ROWS * LDW];
   __shared__ double lds_t[NPW][NS][NS];
@@ -667,7 +674,9 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
   const int col = grp * 16 + role;                      // this lane's column of the LDS stage in node-parallel phases
   const double hT = (1.0 / K) * d.T;
   constexpr int IB = FORM == 1 ? IA : IW;          // the defect row the control enters (v1: the algebraic angle row)
-  const double dcw = MP ? params[pc].dcost : 0.0;  // weight of the l1 move penalty
+  // weight of the l1 move penalty on u and the control before node 0 (v1: the MV is the angle = (aub/2)(u + 1), DCOST on the angle, angle_0 = 0)
+  const double dcw = MP ? (FORM == 1 ? params[pc].dcost * 0.5 * d.aub : params[pc].dcost) : 0.0;
+  constexpr double UINIT = FORM == 1 ? -1.0 : 0.0;
 
   PROF_DECL
   for (int round = 0; round < 64 * (max_iter + 2); round++) {
@@ -697,7 +706,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
           const int k = c * CH + role;
           if (k < K) {
             NodeIn n, dn;
-            load_node<MP>(ic, Kp, K, k, n);
+            load_node<MP>(ic, Kp, K, k, n, UINIT);
             if (first) dn = NodeIn{};             // (no step yet; the step rows are not initialised)
             else load_node<MP>(stp, Kp, K, k, dn);
             trial_node<SCHEME, FORM, MP, TERM>(d, K, Kp, k, n, dn, t, live, in, P);
@@ -850,7 +859,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
           const int k = c * CH + role;
           if (k < K && act) {
             NodeIn n;
-            load_node<MP>(it, Kp, K, k, n);
+            load_node<MP>(it, Kp, K, k, n, UINIT);
             double G[8], E[4], H[10], F[7], fl[7], lt[7], ax, ay;
             ASC_UNROLL
             for (int i = 0; i < 7; i++) lt[i] = SCHEME == 1 ? n.l[i] + n.ln[i] : n.l[i];
@@ -890,7 +899,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
               const MovePivot mvp = move_pivot(n.pp, n.pn, n.zpp, n.zpn, n.lu, dcw, mu, dw);
               stage[(S_C + 7) * LDW + col] = n.u - n.up - n.pp + n.pn;
               stage[(S_RZ + 7) * LDW + col] = (scr[1] + (n.lu - n.lun)) + mu * scr[4];
-              stage[(S_GT + 7) * LDW + col] = -hT * d.alpha * n.l[IW];
+              stage[(S_GT + 7) * LDW + col] = FORM == 1 ? 0.0 : -hT * d.alpha * n.l[IW];
               stage[S_SC * LDW + col] = scr[0];
               stage[(S_SC + 1) * LDW + col] = mvp.Rd;
               stage[(S_SC + 2) * LDW + col] = mvp.gdl;
@@ -940,7 +949,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
               a[IA] = 0.0;
               if (role == IA) {
                 ASC_UNROLL
-                for (int i = 0; i < 7; i++) a[i] = 0.0;
+                for (int i = 0; i < NS; i++) a[i] = 0.0;
               }
             }
             if (SCHEME == 1 && k < K - 1) {   // pull the value function of step k+1 back through Abar = I + cs F_z(z_k): Abar' on every
@@ -972,11 +981,11 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
               ASC_UNROLL
               for (int i = 0; i < NS; i++) a[i] += role == i ? dw : 0.0;
             }
-            // (MP: the extended step Jacobian is [[A, -be e_w], [0, 1]]: its inverse transpose acts as A^-T on the states and
-            //  adds be times the angular-rate component to the control's entry)
+            // (MP: the extended step Jacobian is [[A, -bu e_b], [0, 1]], b the defect row the control enters: its inverse transpose acts as
+            //  A^-T on the states and adds bu times that row's component to the control's entry)
             double b[NS];
             solveAT<FORM>(G, E, cs, a, b);
-            if constexpr (MP) b[7] = a[7] + be * b[IW];
+            if constexpr (MP) b[7] = a[7] + bu * b[IB];
             if (colr) {       // N <- A^-T N A^-1: the columns, transposed through LDS (in order within a wavefront), the columns again
               ASC_UNROLL
               for (int i = 0; i < NS; i++) lds_t[grp][role][i] = b[i];
@@ -985,7 +994,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
               ASC_UNROLL
               for (int l2 = 0; l2 < NS; l2++) t[l2] = lds_t[grp][l2][role];
               solveAT<FORM>(G, E, cs, t, b);
-              if constexpr (MP) b[7] = t[7] + be * b[IW];
+              if constexpr (MP) b[7] = t[7] + bu * b[IB];
             }
             double mw[NS], D, coef;
             if constexpr (MP) {       // the stage's control delta enters the movement equation (row 7) with coefficient one
@@ -1151,7 +1160,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             for (int i = 0; i < NS; i++) ka[i] = w[(size_t)(R_KA + i) * Kp + kn];
             if constexpr (MP) {
               pp_ = it[O_PP * Kp + kn]; pn_ = it[O_PN * Kp + kn]; zpp_ = it[O_ZP * Kp + kn]; zpn_ = it[O_ZN * Kp + kn]; lu_ = it[O_LU * Kp + kn];
-              x0u = -(u_ - (kn > 0 ? it[O_U * Kp + kn - 1] : 0.0) - pp_ + pn_);
+              x0u = -(u_ - (kn > 0 ? it[O_U * Kp + kn - 1] : UINIT) - pp_ + pn_);
             }
             du00 = w[(size_t)R_K0 * Kp + kn] + w[(size_t)(R_K0 + 1) * Kp + kn] * dth + w[(size_t)(R_K0 + 2) * Kp + kn] * dnu3;
             accel<1>(d, z[IX], z[IY], z[IA], z[IM], 0.0, 0.0, ax, ay, G, nullptr);
@@ -1243,7 +1252,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
                 v0 = du00p;
               }
               ASC_UNROLL
-              for (int j = 0; j < 6; j++) stage[(FS * 6 + j) * LDW + col] = -kj[j];
+              for (int j = 0; j < 6; j++) stage[(FS * 6 + j) * LDW + col] = (FORM == 1 && j == IA) ? 0.0 : -kj[j];     // (v1: no coupling to angle_{k-1})
               stage[(FS * 6 + 6) * LDW + col] = 1.0 - ka[7];
               stage[(FS * 6 + NC) * LDW + col] = x0u + v0;
             } else if (SCHEME == 1) {         // du_k = du00 - ka' Abar_k dz_{k-1}
@@ -1389,7 +1398,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
           TrialKeep kp;                       // what the trial point's dual rows need of its primal part (evaluated before the sweep)
           if (kn < K && act) {
             NodeIn n, dn;
-            load_node<MP>(it, Kp, K, kn, n);
+            load_node<MP>(it, Kp, K, kn, n, UINIT);
             ASC_UNROLL
             for (int i = 0; i < 7; i++) { dn.z[i] = stp[(O_Z + i) * Kp + kn]; dn.zp[i] = kn > 0 ? stp[(O_Z + i) * Kp + kn - 1] : 0.0; }
             dn.u = stp[O_U * Kp + kn];
@@ -1613,6 +1622,7 @@ static void launch_solve(int scheme, int form, int mp, long batch, hipStream_t s
     return;
   }
   if (mp && scheme == 1) hipLaunchKernelGGL((p_solve<1, 0, 1>), grid, block, 0, stream, dp, batch, g, w, max_iter, tol);
+  else if (mp && form == 1) hipLaunchKernelGGL((p_solve<0, 1, 1>), grid, block, 0, stream, dp, batch, g, w, max_iter, tol);
   else if (mp) hipLaunchKernelGGL((p_solve<0, 0, 1>), grid, block, 0, stream, dp, batch, g, w, max_iter, tol);
   else if (scheme == 1) hipLaunchKernelGGL((p_solve<1, 0, 0>), grid, block, 0, stream, dp, batch, g, w, max_iter, tol);
   else if (form == 1) hipLaunchKernelGGL((p_solve<0, 1, 0>), grid, block, 0, stream, dp, batch, g, w, max_iter, tol);
@@ -1625,7 +1635,7 @@ static void launch_solve(int scheme, int form, int mp, long batch, hipStream_t s
 int persist_run_nested(const ascent_params *dp, long batch, int scheme, int form, int mp, int term, const int *levels, int nlev, double *ws, const double *dguess, int warm,
                        int max_iter, double tol, double tol_coarse, double mu0, double mu_first, double mu_next, double *dtraj,
                        double *dtf, int *dstatus, int *diters, double *dblob, hipStream_t stream, char *err, size_t errlen) {
-  if ((mp || term == 2) && form != 0) { snprintf(err, errlen, "the persistent kernel carries the move penalty and terminal 2 for formulation 0 only"); return ASCENT_E_ARG; }
+  if (term == 2 && form != 0) { snprintf(err, errlen, "the persistent kernel carries terminal 2 for formulation 0 only"); return ASCENT_E_ARG; }
   double *region[2] = {ws, (double *)((char *)ws + persist_region1_offset(levels, batch, mp))};
   PGeo g = geo_of(levels[nlev - 1] - 1, form, mp, term);
   double *w = region[(nlev - 1) & 1];
@@ -1652,7 +1662,7 @@ int persist_run_nested(const ascent_params *dp, long batch, int scheme, int form
 // not carry, are set around the iterate's own movement as every warm start sets them.)
 int persist_probe(const ascent_params *dp, long batch, int scheme, int form, int mp, int term, int K, double *ws, const double *diterate, const double *dmu, const double *ddw,
                   double *dstep, int *dinertia, hipStream_t stream, char *err, size_t errlen) {
-  if ((mp || term == 2) && form != 0) { snprintf(err, errlen, "the persistent kernel carries the move penalty and terminal 2 for formulation 0 only"); return ASCENT_E_ARG; }
+  if (term == 2 && form != 0) { snprintf(err, errlen, "the persistent kernel carries terminal 2 for formulation 0 only"); return ASCENT_E_ARG; }
   const PGeo g = geo_of(K, form, mp, term);
   const dim3 ng((unsigned)((g.Kp + WAVE - 1) / WAVE), (unsigned)batch);
   hipLaunchKernelGGL(p_init, ng, dim3(WAVE), 0, stream, dp, batch, g, ws, diterate, 2, 0.1, dmu, ddw, 1);

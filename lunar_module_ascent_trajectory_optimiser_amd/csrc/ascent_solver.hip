@@ -932,7 +932,7 @@ bool use_dense_path(const ascent_opts *o, int64_t batch) {
   if (o->scheme == 2 || o->solver_path == ASCENT_PATH_DENSE) return true;
   const char *e = getenv("ASCENT_PIPELINE");
   // (the move penalty and terminal 2 exist in the persistent kernel and in the dense-block path: an override that names any other family means the dense one)
-  if ((o->move_penalty || o->terminal == 2) && ((e && strcmp(e, "persist")) || getenv("ASCENT_FACTOR"))) return true;
+  if ((o->move_penalty || o->terminal == 2) && o->formulation == 0 && ((e && strcmp(e, "persist")) || getenv("ASCENT_FACTOR"))) return true;
   if (e) return !strcmp(e, "dense") && o->formulation == 0;
   // A handful of NLPs cannot fill the hand-tuned kernels (one wavefront per four NLPs, serial over the nodes: 2.8 ms at
   // N=200, 7.3 ms at N=600, 25-31 ms at N=2000 for up to 8 NLPs); the dense-block path with its Newton systems solved by
@@ -1088,7 +1088,7 @@ int check_common(const ascent_params *p, int64_t batch, const ascent_opts *o, in
   if (o->terminal == 2 && o->formulation != 0) { snprintf(g_err, sizeof g_err, "terminal 2 has formulation 0 only"); return ASCENT_E_ARG; }
   if (o->solver_path != ASCENT_PATH_AUTO && o->solver_path != ASCENT_PATH_DENSE) { snprintf(g_err, sizeof g_err, "solver_path must be 0 (automatic) or ASCENT_PATH_DENSE"); return ASCENT_E_ARG; }
   if ((o->scheme == 2 || o->solver_path == ASCENT_PATH_DENSE) && o->formulation != 0) { snprintf(g_err, sizeof g_err, "the dense-block path (scheme 2 / ASCENT_PATH_DENSE) has formulation 0 only"); return ASCENT_E_ARG; }
-  if (o->move_penalty && o->formulation != 0) { snprintf(g_err, sizeof g_err, "move_penalty = 1 is carried for formulation 0 only"); return ASCENT_E_ARG; }
+  if (o->move_penalty && o->formulation != 0 && (o->scheme != 0 || o->solver_path == ASCENT_PATH_DENSE)) { snprintf(g_err, sizeof g_err, "move_penalty = 1 with formulation 1: scheme 0, persistent kernel only"); return ASCENT_E_ARG; }
   if (o->move_penalty != 0 && o->move_penalty != 1) { snprintf(g_err, sizeof g_err, "move_penalty must be 0 or 1"); return ASCENT_E_ARG; }
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) { snprintf(g_err, sizeof g_err, "no HIP device available"); return ASCENT_E_NODEVICE; }
@@ -1187,6 +1187,7 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
   const bool pcr = dense && o->terminal != 2 && use_pcr_newton(batch, o->move_penalty != 0);     // (terminal 2: the Riccati form carries it)
   const bool persist = !dense && use_persist_path(o, batch);
   const bool split = o->scheme == 1 || o->formulation == 1 || use_split_pipeline(batch);
+  if ((o->move_penalty || o->terminal == 2) && !persist && !dense) { snprintf(g_err, sizeof g_err, "move_penalty / terminal 2 exist in the persistent kernel and the dense-block path only (ASCENT_PIPELINE / ASCENT_FACTOR name another family)"); return ASCENT_E_ARG; }
   int levels[8];
   const int nlev = nested_levels(o, levels);
   const int slot = slot_for(device_id, stream);

@@ -398,9 +398,10 @@ class GEKKO:
         if terminal:
             extra["terminal"] = terminal
         dcost = float(P.dcost)
-        # the script's own MV.DCOST is part of the model it declares: applied (ascent_opts.move_penalty) unless switched off; the
-        # v1 formulation (the angle is the MV) has no move penalty in the library
-        apply_dcost = bool(int(getattr(self.options, "ASCENT_DCOST", 1))) and dcost > 0.0 and not self._formulation
+        # the script's own MV.DCOST is part of the model it declares: applied (ascent_opts.move_penalty) unless switched off -- in the
+        # current script on angledoubledot (Launch_Optimiser.py:99), in the v1 script on the angle itself (PDF p26); the v1
+        # formulation carries it with the reference's scheme only (backward Euler)
+        apply_dcost = bool(int(getattr(self.options, "ASCENT_DCOST", 1))) and dcost > 0.0 and not (self._formulation and scheme)
         if apply_dcost:
             extra["move_penalty"] = True
         if self._solver is not None:      # a caller-supplied solver hook (tests, CPU rehearsals) gets only the options it declares
@@ -415,7 +416,7 @@ class GEKKO:
             GEKKO._dcost_warned = True
             import warnings
             warnings.warn(f"MV DCOST = {dcost:g} (Launch_Optimiser.py:99) is NOT applied ("
-                          + ("the v1 formulation has no move penalty in libascent" if self._formulation else "m.options.ASCENT_DCOST = 0")
+                          + ("the v1 formulation carries the move penalty with backward Euler only" if (self._formulation and scheme) else "m.options.ASCENT_DCOST = 0")
                           + "): applied, it shifts the nominal t_f by +1.5e-3 s (3.5e-6 relative; the parity bar is 1e-4) -- see "
                           "DESIGN.md", stacklevel=2)
         if disp:
@@ -438,8 +439,8 @@ class GEKKO:
         tf.value = [float(res.tf[0])] * nt
         # OBJFCNVAL reports the objective that was minimised: tf, plus the move penalty when it is applied
         obj = float(res.tf[0])
-        if apply_dcost and hasattr(res, "field"):
-            u_ = np.asarray(res.field("angledoubledot")[:, 0], dtype=float)
+        if apply_dcost and hasattr(res, "field"):      # (v1: the MV is the angle, in the script's own units)
+            u_ = np.asarray(res.field("angle" if self._formulation else "angledoubledot")[:, 0], dtype=float)
             obj += dcost * float(np.abs(np.diff(u_)).sum())
         self.options.APPSTATUS, self.options.SOLVESTATUS, self.options.OBJFCNVAL = 1, 1, obj
         self.options.ITERATIONS = int(res.iters[0])

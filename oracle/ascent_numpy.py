@@ -395,6 +395,67 @@ def _factor_with_inertia(Kmat, n, m):
     return lu, bool(sym and np.all(np.isfinite(dU)) and (dU > 0).sum() == n and (dU < 0).sum() == m)
 
 
+class MovePenaltyNLP:
+    """Any of this module's NLPs plus the MV's DCOST (LO:99; v1 script: `angle.DCOST = 1e-5`, PDF p26) as APMonitor documents it:
+    + dcost * sum_k |c_k - c_{k-1}| over the control c (c_0 = c_init), with a slack pair per step -- c_k - c_{k-1} = p_k - n_k,
+    p, n >= 0, cost dcost (p_k + n_k) -- as explicit unknowns and rows; nothing is reduced.  Unknowns [base | p | n]; equalities
+    [base rows but the last three | movement equations | the base's last three (terminal) rows], so that `solve_ip` finds the two
+    terminal inequality rows where it expects them.  The independent anchor of the stage-structured implementations (C
+    restatement, HIP kernels) for the formulations oracle/ascent_general.py does not restate (the v1 script)."""
+
+    def __init__(self, base, ctrl_cols, dcost: float, c_init: float = 0.0):
+        self.base, self.cc, self.dcost, self.c_init = base, np.asarray(ctrl_cols), float(dcost), float(c_init)
+        K = len(self.cc)
+        self.Kc = K
+        self.n, self.m = base.n + 2 * K, base.m + K
+        self.ip, self.in_ = base.n + np.arange(K), base.n + K + np.arange(K)
+        self.rmove = base.m - 3 + np.arange(K)
+        self.lb = np.concatenate([base.lb, np.zeros(2 * K)])
+        self.ub = np.concatenate([base.ub, np.full(2 * K, np.inf)])
+        self.itf, self.is1, self.is2 = base.itf, base.is1, base.is2
+        self.P, self.nt, self.K = base.P, base.nt, base.K
+
+    def objective(self, v):
+        return self.base.objective(v[: self.base.n]) + self.dcost * (v[self.ip].sum() + v[self.in_].sum())
+
+    def grad_objective(self, v):
+        g = np.concatenate([self.base.grad_objective(v[: self.base.n]), np.full(2 * self.Kc, self.dcost)])
+        return g
+
+    def constraints(self, v):
+        cb = self.base.constraints(v[: self.base.n])
+        c = v[self.cc]
+        mv = c - np.concatenate([[self.c_init], c[:-1]]) - v[self.ip] + v[self.in_]
+        return np.concatenate([cb[:-3], mv, cb[-3:]])
+
+    def jacobian(self, v):
+        import scipy.sparse as sp_
+        Jb = self.base.jacobian(v[: self.base.n]).tocsr()
+        K = self.Kc
+        pad = sp_.csr_matrix((Jb.shape[0], 2 * K))
+        Jb = sp_.hstack([Jb, pad]).tocsr()
+        rows = np.concatenate([np.arange(K), np.arange(1, K), np.arange(K), np.arange(K)])
+        cols = np.concatenate([self.cc, self.cc[:-1], self.ip, self.in_])
+        vals = np.concatenate([np.ones(K), -np.ones(K - 1), -np.ones(K), np.ones(K)])
+        Jm = sp_.csr_matrix((vals, (rows, cols)), shape=(K, self.n))
+        return sp_.vstack([Jb[:-3], Jm, Jb[-3:]]).tocsc()
+
+    def hessian(self, v, lam):
+        import scipy.sparse as sp_
+        lb_ = np.concatenate([lam[: self.base.m - 3], lam[-3:]])
+        Hb = self.base.hessian(v[: self.base.n], lb_)
+        return sp_.block_diag([Hb, sp_.csr_matrix((2 * self.Kc, 2 * self.Kc))]).tocsc()
+
+    def initial_guess(self, **kw):
+        return np.concatenate([self.base.initial_guess(**kw), np.full(2 * self.Kc, 0.1)])
+
+    def outputs(self, v):
+        return self.base.outputs(v[: self.base.n])
+
+    def split(self, v):
+        return self.base.split(v[: self.base.n])
+
+
 def solve_ip(nlp: AscentNLP, v0=None, tol=1e-9, max_iter=300, mu0=0.1, verbose=False, inertia="curvature"):
     """inertia: "curvature" = accept a step when dx'(W+Sigma+dw)dx > 0 along it (the test this oracle has always used: cheap,
     sufficient on the single-phase problems); "exact" = IPOPT's rule, the KKT matrix must have exactly n positive and m

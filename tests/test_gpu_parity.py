@@ -198,6 +198,47 @@ def test_move_penalty_in_the_persistent_kernel_matches_the_oracle_on_a_sweep(cor
     assert np.all(warm.status == 0) and warm.iters.max() <= 12 and np.abs(warm.tf - full.tf).max() <= 1e-8
 
 
+def test_move_penalty_with_the_v1_formulation(coracle):
+    """The v1 script's own `angle.DCOST = 1e-5` (PDF p26): ascent_opts.move_penalty with formulation 1 in the persistent kernel
+    (p_solve<0,1,1>: the control enters the algebraic angle row, weight dcost * angle_ub/2 on u, u before node 0 = -1).
+    Step level against the C restatement (1e-9); solve level against tests/golden/dcost_fixtures.json["v1_cases"] -- the v1
+    formulation's own numpy NLP with explicit slack pairs, generic LU (t_f to 2e-8) -- and against the C restatement on a sweep
+    (identical iteration counts, t_f to 1e-9, the median to 1e-14)."""
+    import json, os
+    base = A.AscentParams(**V1)
+    S = A.sweep_isp_drymass(2, 3, base=base)
+    S[:, 15] = [1e-5, 1e-5, 1e-3, 1e-4, 1e-5, 1e-2]
+    nt = 60
+    blobs = _interior_blobs(coracle, S, nt, 0, 1)
+    mu = np.array([0.1, 0.02, 1e-3, 0.05, 1e-6, 0.2]); dw = np.array([0.0, 0.0, 1e-2, 1.0, 0.0, 1e-4])
+    step, inertia = A.kkt_step(S, blobs, mu, dw, nt, path="persist", formulation=1, move_penalty=True)
+    n_ok = 0
+    for b in range(len(S)):
+        rc, ref = coracle.newton_step(S[b], nt, np.ascontiguousarray(blobs[:, b]), mu[b], dw[b], formulation=1, move_penalty=True)
+        assert rc == inertia[b]
+        if rc == 0:
+            n_ok += 1
+            assert np.abs(step[:, b] - ref).max() <= 1e-9 * max(1.0, np.abs(ref).max())
+    coracle.set_formulation(0)
+    assert n_ok >= 4
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "dcost_fixtures.json")))
+    for c in fx["v1_cases"]:
+        P = A.AscentParams(**c["params"])
+        for on in (False, True):
+            r = A.solve_batch(P, c["nt"], tol=1e-9, formulation=1, move_penalty=on, max_iter=500)
+            ref = c["on" if on else "off"]
+            assert r.status[0] == 0 and abs(r.tf[0] - ref["tf"]) <= 2e-8, (c["nt"], c["dcost"], on, r.tf[0], ref["tf"])
+            ang = r.traj[6, :, 0]
+            assert abs(np.abs(np.diff(ang)).sum() - ref["total_variation"]) <= 2e-3 * ref["total_variation"]
+    S2 = A.sweep_isp_drymass(5, 4, base=base)
+    S2[:, 15] = 1e-5
+    r = A.solve_batch(S2, NT, tol=1e-9, formulation=1, move_penalty=True)
+    ref = coracle.solve_batch(S2, NT, 300, 1e-9, formulation=1, move_penalty=True)
+    coracle.set_formulation(0)
+    assert np.all(r.status == 0) and np.array_equal(r.iters, ref["iters"]) and np.abs(r.tf - ref["tf"]).max() <= 1e-9
+    assert np.median(np.abs(r.tf - ref["tf"])) <= 1e-14
+
+
 @pytest.mark.parametrize("scheme,mp", [(0, False), (1, False), (0, True)])
 def test_kkt_step_with_terminal2_persistent_kernel_equals_dense_path(coracle, monkeypatch, scheme, mp):
     """ascent_opts.terminal = 2 (burnout anywhere on the ellipse) at step level: one Newton step through one round of

@@ -350,3 +350,25 @@ def test_c_oracle_move_penalty_matches_fixtures_and_generic_lu(coracle):
             for lo, hi in ((0, 8 * K), (8 * K, 15 * K), (15 * K, 21 * K), (21 * K, 21 * K + 10)):
                 assert np.abs(st[lo:hi] - lu[lo:hi]).max() <= 1e-9 * max(1.0, np.abs(lu[lo:hi]).max())
     coracle.set_scheme(0)
+
+
+def test_c_oracle_v1_move_penalty_matches_the_unreduced_numpy_nlp(coracle):
+    """The v1 script's `angle.DCOST = 1e-5` (PDF p26) in the plain-C restatement (formulation 1 embedded in the 7-state layout:
+    weight dcost * angle_ub/2 on u, u before node 0 = -1) against tests/golden/dcost_fixtures.json["v1_cases"]: the hand-written
+    numpy NLP of the v1 formulation (5 states + the angle as control) with slack pairs and movement equations as explicit
+    unknowns and rows, generic sparse LU (scripts/make_v1_dcost_fixture.py).  t_f to 1e-9, total variation of the angle to 0.2 %."""
+    import json
+    fx = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "dcost_fixtures.json")))
+    assert len(fx["v1_cases"]) >= 3
+    for c in fx["v1_cases"]:
+        p16 = coracle.pack_params(Params(**c["params"]))
+        for on in (False, True):
+            r = coracle.solve_batch(p16[None], c["nt"], 800, 1e-10, formulation=1, move_penalty=on)
+            ref = c["on" if on else "off"]
+            ang = r["traj"][0, 6, :]
+            assert r["status"][0] == 0 and abs(r["tf"][0] - ref["tf"]) <= 1e-9, (c["nt"], c["dcost"], on, r["tf"][0], ref["tf"])
+            assert abs(np.abs(np.diff(ang)).sum() - ref["total_variation"]) <= 2e-3 * ref["total_variation"]
+            if on:
+                assert np.abs(ang[1:] - np.array(ref["angle"])).max() <= 2e-3
+        assert c["on"]["tf"] > c["off"]["tf"] and c["on"]["total_variation"] < c["off"]["total_variation"]
+    coracle.set_formulation(0)
