@@ -79,7 +79,7 @@ enum {
 enum { ST_TRIAL = 0, ST_FACTOR = 1, ST_FACTORED = 2, ST_DONE = 3 };
 
 struct PGeo {
-  int K, Kp, nch, form, mp, term;      // term: ascent_opts.terminal 2 (burnout anywhere on the ellipse) or 0
+  int K, Kp, nch, form, mp, term, wide;      // wide: one NLP per wavefront, 64-node chunks; term: ascent_opts.terminal 2 (burnout anywhere on the ellipse) or 0
   __host__ __device__ int nit() const { return mp ? Lay<1>::NIT : Lay<0>::NIT; }
   __host__ __device__ int r_st() const { return 2 * nit(); }
   __host__ __device__ int nrows() const { return mp ? Lay<1>::NROWS : Lay<0>::NROWS; }
@@ -114,6 +114,10 @@ ASC_DEV void wsync() {
 ASC_DEV double gsum16(double v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); return v; }
 ASC_DEV double gmax16(double v) { v = fmax(v, __shfl_xor(v, 1)); v = fmax(v, __shfl_xor(v, 2)); v = fmax(v, __shfl_xor(v, 4)); return fmax(v, __shfl_xor(v, 8)); }
 ASC_DEV double gmin16(double v) { v = fmin(v, __shfl_xor(v, 1)); v = fmin(v, __shfl_xor(v, 2)); v = fmin(v, __shfl_xor(v, 4)); return fmin(v, __shfl_xor(v, 8)); }
+// ... or over the whole wavefront (WIDE: one NLP per wavefront)
+template <int WIDE> ASC_DEV double gsumW(double v) { v = gsum16(v); if constexpr (WIDE) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); } return v; }
+template <int WIDE> ASC_DEV double gmaxW(double v) { v = gmax16(v); if constexpr (WIDE) { v = fmax(v, __shfl_xor(v, 16)); v = fmax(v, __shfl_xor(v, 32)); } return v; }
+template <int WIDE> ASC_DEV double gminW(double v) { v = gmin16(v); if constexpr (WIDE) { v = fmin(v, __shfl_xor(v, 16)); v = fmin(v, __shfl_xor(v, 32)); } return v; }
 
 ASC_DEV Scal lds_scal(const double *sc, int r0) {
   Scal s;
@@ -480,6 +484,12 @@ struct Part {
     l1 = gsum16(l1); zsum = gsum16(zsum); rth = gsum16(rth); c1 = gsum16(c1); sl = gsum16(sl);
     if constexpr (MP) mv = gsum16(mv);
   }
+  template <int MP, int WIDE>
+  ASC_DEV void reduceW() {
+    rd = gmaxW<WIDE>(rd); cinf = gmaxW<WIDE>(cinf); pmin = gminW<WIDE>(pmin); pmax = gmaxW<WIDE>(pmax);
+    l1 = gsumW<WIDE>(l1); zsum = gsumW<WIDE>(zsum); rth = gsumW<WIDE>(rth); c1 = gsumW<WIDE>(c1); sl = gsumW<WIDE>(sl);
+    if constexpr (MP) mv = gsumW<WIDE>(mv);
+  }
 };
 struct TrialCtx {       // what the trial point of an NLP needs besides the node data
   double alpha, adu, mlo, mhi, dt, be, hT, dcw;
@@ -643,7 +653,7 @@ ASC_DEV void trial_node(const Der &d, int K, int Kp, int k, const NodeIn &n, con
 #define PROF_END do { } while (0)
 #endif
 
-template <int SCHEME, int FORM, int MP = 0, int TERM = 0>
+template <int SCHEME, int FORM, int MP = 0, int TERM = 0, int WIDE = 0>
 __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, long batch, PGeo g, double *ws, int max_iter, double tol) {
   using L = Lay<MP>;
   constexpr int NS = L::NS, NIT = L::NIT, R_ST = L::R_ST, R_KA = L::R_KA, R_K0 = L::R_K0, NROWS = L::NROWS;
@@ -656,14 +666,20 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
   __shared__ double lds_d[NPW][3][8];                   // (row 2 stays zero)
   __shared__ double lsc[NPW][NSCAL];
   __shared__ double lds_c[NPW][8];                      // adjoint phase: the multiplier step of the first node of the chunk above
+  // WIDE = 1 (batches that leave SIMDs idle: one NLP per wavefront): the node-parallel phases take 64 nodes at a time on the 64
+  // lanes instead of 4 NLPs x 16 nodes; the four 16-lane groups then run the SAME serial sweeps side by side (identical values,
+  // identical stores) over the 64 steps of a chunk, and sums over the nodes run over the whole wavefront.
+  constexpr int CHN = WIDE ? 64 : CH;                   // nodes per chunk
   const int lane = threadIdx.x, grp = lane >> 4, role = lane & 15;
-  const long p = (long)blockIdx.x * NPW + grp;
+  const int nl = WIDE ? lane : role;                    // this lane's node within a chunk
+  const int cbase = WIDE ? 0 : grp * 16;                // first column of this lane's NLP in the LDS stage
+  const long p = WIDE ? (long)blockIdx.x : (long)blockIdx.x * NPW + grp;
   const bool live = p < batch;
   const long pc = live ? p : batch - 1;                 // dead groups shadow the last NLP and never store
   const int K = g.K, Kp = g.Kp, nch = g.nch;
   double *w = ws + (size_t)pc * g.nlp_doubles();
   double *gsc = w + (size_t)NROWS * Kp;
-  double *sc = lsc[grp];
+  double *sc = lsc[WIDE ? 0 : grp];
   const Der d = TERM == 2 ? derive_t(params[pc], 2) : derive(params[pc]);      // (TERM = 2: burnout anywhere on the (r_peri, r_apo) ellipse)
   static_assert(TERM == 0 || (TERM == 2 && FORM == 0), "terminal 2 is carried for the current formulation");
   for (int r = role; r < NSCAL; r += 16) sc[r] = gsc[r];
@@ -703,7 +719,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
         t.alpha = alpha; t.adu = adu; t.mlo = mlo; t.mhi = mhi; t.dt = dt; t.be = be; t.hT = hT; t.first = first; t.stt = stt; t.dcw = dcw;
         P.clear();
         for (int c = 0; c < nch; c++) {
-          const int k = c * CH + role;
+          const int k = c * CHN + nl;
           if (k < K) {
             NodeIn n, dn;
             load_node<MP>(ic, Kp, K, k, n, UINIT);
@@ -712,7 +728,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             trial_node<SCHEME, FORM, MP, TERM>(d, K, Kp, k, n, dn, t, live, in, P);
           }
         }
-        P.template reduce16<MP>();
+        P.template reduceW<MP, WIDE>();
       }
       double rd = P.rd, cinf = P.cinf, pmin = P.pmin, pmax = P.pmax, l1 = P.l1, zsum = P.zsum;
       const double rth = 1.0 + P.rth, c1 = P.c1, sl = P.sl;
@@ -856,7 +872,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
       for (int c = nch - 1; c >= 0; c--) {
         // ---- node-parallel: the blocks of the 16 nodes of this chunk -------------------------------------------------
         {
-          const int k = c * CH + role;
+          const int k = c * CHN + nl;
           if (k < K && act) {
             NodeIn n;
             load_node<MP>(it, Kp, K, k, n, UINIT);
@@ -914,7 +930,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
         wsync();
         PROF(1);
         if (probe_rows) {      // the rows the sweep would gather -- Jacobian block, Hessian block (bound terms included), defects -- as they
-          const int k = c * CH + role;                    // stand in LDS, into the step / gain rows of the workspace (p_probe_rows_out)
+          const int k = c * CHN + nl;                    // stand in LDS, into the step / gain rows of the workspace (p_probe_rows_out)
           if (k < K && act && live) {
             ASC_UNROLL
             for (int i = 0; i < 8; i++) w[(size_t)(R_ST + i) * Kp + k] = stage[(S_G + i) * LDW + col];
@@ -928,10 +944,10 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
         }
         // ---- serial: the 16 steps of the chunk, backwards; 16 lanes per NLP (the arithmetic of q_factor_wide) -----------
         if (act) {
-          for (int jj = CH - 1; jj >= 0; jj--) {
-            const int k = c * CH + jj;
+          for (int jj = CHN - 1; jj >= 0; jj--) {
+            const int k = c * CHN + jj;
             if (k >= K) continue;
-            const int cj = grp * 16 + jj;
+            const int cj = cbase + jj;
             double gq[NS];
             ASC_UNROLL
             for (int i = 0; i < NS; i++) gq[i] = stage[grow[i] + cj];
@@ -1049,7 +1065,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
         PROF(2);
         // ---- flush the feedback gains of the chunk (node-parallel) ---------------------------------------------------------
         {
-          const int k = c * CH + role;
+          const int k = c * CHN + nl;
           if (k < K && act) {
             if (live) {
               ASC_UNROLL
@@ -1067,8 +1083,8 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
       }
       // ---- border: the 2x2 Schur complement in (theta, nu3); inertia ---------------------------------------------------------
       const double U0 = bcast16<RL>(U), U1 = bcast16<RL + 1>(U), V1 = bcast16<RL + 1>(V), U2 = bcast16<RL + 2>(U), V2 = bcast16<RL + 2>(V);
-      k10 = gsum16(k10); k11 = gsum16(k11); k12 = gsum16(k12); k20 = gsum16(k20); k22 = gsum16(k22);
-      bad = (int)gmax16((double)bad);
+      k10 = gsumW<WIDE>(k10); k11 = gsumW<WIDE>(k11); k12 = gsumW<WIDE>(k12); k20 = gsumW<WIDE>(k20); k22 = gsumW<WIDE>(k22);
+      bad = (int)gmaxW<WIDE>((double)bad);
       if (probe_rows) {
         if (act && role == 0) sc[X_STATE] = ST_DONE;
       } else if (act) {
@@ -1139,7 +1155,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
         double rmax = 0.0, gsum = 0.0, adu = 1.0, gmove = 0.0, clu = 0.0;
         double dzK[7] = {0, 0, 0, 0, 0, 0, 0};
         for (int c = 0; c < nch; c++) {
-          const int kn = c * CH + role;
+          const int kn = c * CHN + nl;
           const bool on = kn < K && act;
           double a_ = 0.5, m_ = 0.5, u_ = 0.0, zb[6] = {1, 1, 1, 1, 1, 1};
           double G[8], Gp[8], E[4], x0[7], ka[NS], du00 = 0.0;       // (Gp: scheme 1 only, the Jacobian block of node k-1)
@@ -1183,12 +1199,12 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
           // dz_m: inclusive prefix sum of x0_m over the nodes of the NLP (16 here, the chunks before in carry_m)
           double incl = x0[IM];
           ASC_UNROLL
-          for (int sft = 1; sft < 16; sft *= 2) {
-            const double t = __shfl_up(incl, sft, 16);
-            if (role >= sft) incl += t;
+          for (int sft = 1; sft < CHN; sft *= 2) {
+            const double t = __shfl_up(incl, sft, CHN);
+            if (nl >= sft) incl += t;
           }
           const double dzm_k = carry_m + incl, dzm_p = dzm_k - x0[IM];
-          carry_m += bcast16<15>(incl);
+          carry_m += WIDE ? __shfl(incl, 63) : bcast16<15>(incl);
           if (on) {
             const double du00p = du00 - ka[IM] * dzm_p;
             double rvx[7], rvy[7];
@@ -1271,9 +1287,9 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
           wsync();
           PROF(4);
           if (act) {
-            const int jn = min(CH, K - c * CH);
+            const int jn = min(CHN, K - c * CHN);
             for (int jj = 0; jj < jn; jj++) {
-              const int cj = grp * 16 + jj;
+              const int cj = cbase + jj;
               const double *sj = stage + fbase + cj;
               const double m0 = sj[0], m1 = sj[LDW], m2 = sj[2 * LDW], m3 = sj[3 * LDW], m4 = sj[4 * LDW], m5 = sj[5 * LDW], vv = sj[NC * LDW];
               const double b0 = bcast16<0>(yown), b1 = bcast16<1>(yown), b2 = bcast16<2>(yown), b3 = bcast16<3>(yown),
@@ -1323,7 +1339,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
               // The movement multiplier from the stage control's own stationarity row, d lambda_u = Rd ddelta + gdl, then the slack pair:
               // the slack with the larger curvature from its own row (well conditioned), the other one from ddelta = dp - dn (its own row
               // divides a difference of two nearly equal numbers by a curvature that vanishes for an inactive slack)
-              const double du_p = role > 0 ? outb[7 * LDW + col - 1] : carry_u;
+              const double du_p = nl > 0 ? outb[7 * LDW + col - 1] : carry_u;
               const double ddel = (du - du_p) - x0u;
               const MovePivot mvp = move_pivot(pp_, pn_, zpp_, zpn_, lu_, dcw, mu, dw);
               const double dlu = mvp.Rd * ddel + mvp.gdl;
@@ -1341,14 +1357,14 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
               }
             }
           }
-          if constexpr (MP) carry_u = outb[7 * LDW + grp * 16 + 15];       // the control step of the chunk's last node
+          if constexpr (MP) carry_u = outb[7 * LDW + cbase + CHN - 1];       // the control step of the chunk's last node
           wsync();
           PROF(6);
         }
-        rmax = gmax16(rmax); gsum = gsum16(gsum); adu = gmin16(adu);
-        if constexpr (MP) { gmove = gsum16(gmove); clu = gsum16(clu); }
+        rmax = gmaxW<WIDE>(rmax); gsum = gsumW<WIDE>(gsum); adu = gminW<WIDE>(adu);
+        if constexpr (MP) { gmove = gsumW<WIDE>(gmove); clu = gsumW<WIDE>(clu); }
         ASC_UNROLL
-        for (int i = 0; i < 7; i++) dzK[i] = gsum16(dzK[i]);          // only the lane of the last node holds non-zeros
+        for (int i = 0; i < 7; i++) dzK[i] = gsumW<WIDE>(dzK[i]);          // only the lane of the last node holds non-zeros
         // ---- the scalars of the step and the step lengths: known once the primal step is (the adjoint below only adds the
         //      multiplier steps), so that the adjoint phase can evaluate the first trial point of the line search as it goes ----
         double zK[7];
@@ -1393,7 +1409,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
         double lown = 0.0;
         double cl = 0.0, ccl = 0.0;
         for (int c = nch - 1; c >= 0; c--) {
-          const int kn = c * CH + role;
+          const int kn = c * CHN + nl;
           double ccn[7] = {0, 0, 0, 0, 0, 0, 0};
           TrialKeep kp;                       // what the trial point's dual rows need of its primal part (evaluated before the sweep)
           if (kn < K && act) {
@@ -1496,9 +1512,9 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
           wsync();
           PROF(7);
           if (act) {
-            const int jj0 = min(CH, K - c * CH) - 1;
+            const int jj0 = min(CHN, K - c * CHN) - 1;
             for (int jj = jj0; jj >= 0; jj--) {
-              const int cj = grp * 16 + jj;
+              const int cj = cbase + jj;
               const double *sj = stage + abase + cj;
               const double n0 = sj[0], n1 = sj[LDW], n2 = sj[2 * LDW], n3 = sj[3 * LDW], n4 = sj[4 * LDW], wv = sj[5 * LDW];
               const double b0 = bcast16<0>(lown), b1 = bcast16<1>(lown), b2 = bcast16<2>(lown), b3 = bcast16<3>(lown), b4 = bcast16<4>(lown);
@@ -1513,7 +1529,7 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
             ASC_UNROLL
             for (int i = 0; i < 7; i++) {
               dl[i] = outb[i * LDW + col];
-              dln[i] = kn + 1 < K ? (role < 15 ? outb[i * LDW + col + 1] : lds_c[grp][i]) : 0.0;
+              dln[i] = kn + 1 < K ? (nl < CHN - 1 ? outb[i * LDW + col + 1] : lds_c[WIDE ? 0 : grp][i]) : 0.0;
               ccl += ccn[i] * dl[i];            // c . dlambda: no recurrence, summed here
             }
             if (live) {
@@ -1526,9 +1542,9 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
           // ---- node-parallel: the step of the chunk is complete -> the dual rows of its trial point (the iterate's multipliers
           //      come from HBM again rather than being held across the sweep) ------------------------------------------------------
           if (kn < K && act) {
-            if (role == 0) {
+            if (nl == 0) {
               ASC_UNROLL
-              for (int i = 0; i < 7; i++) lds_c[grp][i] = dl[i];
+              for (int i = 0; i < 7; i++) lds_c[WIDE ? 0 : grp][i] = dl[i];
             }
             double l[7], ln[7], lu = 0.0, lun = 0.0;
             ASC_UNROLL
@@ -1544,9 +1560,9 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
           }
           PROF(0);
         }
-        P.template reduce16<MP>();
+        P.template reduceW<MP, WIDE>();
         // ---- scalars of the step, merit bookkeeping -------------------------------------------------------------------------
-        ccl = gsum16(ccl);
+        ccl = gsumW<WIDE>(ccl);
         if (act) {
           cl += ccl;
           const Terminal &tm = tmK;
@@ -1589,20 +1605,28 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
 
 namespace ascent {
 
-static PGeo geo_of(int K, int form = 0, int mp = 0, int term = 0) {
+// wide: one NLP per wavefront, 64-node chunks (node arrays padded to a multiple of 64); otherwise four NLPs per wavefront, 16-node chunks
+static PGeo geo_of(int K, int form = 0, int mp = 0, int term = 0, int wide = 0) {
   PGeo g;
-  g.K = K; g.nch = (K + CH - 1) / CH; g.Kp = g.nch * CH; g.form = form; g.mp = mp ? 1 : 0; g.term = term == 2 ? 2 : 0;
+  const int ch = wide ? 64 : CH;
+  g.K = K; g.nch = (K + ch - 1) / ch; g.Kp = g.nch * ch; g.form = form; g.mp = mp ? 1 : 0; g.term = term == 2 ? 2 : 0; g.wide = wide ? 1 : 0;
   return g;
+}
+// Batches that cannot give every SIMD a wavefront of four NLPs (MI355X: 256 CUs x 4 SIMDs) run one NLP per wavefront; the v1
+// formulation, the trapezoid with the move penalty and terminal 2 keep the four-NLP form (fewer instantiations of a large kernel).
+static int use_wide(long batch, int scheme, int form, int mp, int term) {
+  if (const char *e = getenv("ASCENT_PERSIST_WIDE")) return e[0] == '1' && form == 0 && term == 0 && !(scheme == 1 && mp);
+  return batch <= 1024 && form == 0 && term == 0 && !(scheme == 1 && mp);
 }
 
 // One grid level's workspace, rounded up to a multiple of 256 bytes: the two regions of the nested iteration are laid out
 // back to back with exactly these sizes (persist_region1_offset below is the one place that says where the second one starts).
-size_t persist_ws_bytes(int K, long batch, int mp) {
-  const size_t b = (size_t)batch * geo_of(K, 0, mp).nlp_doubles() * sizeof(double) + 64;
+size_t persist_ws_bytes(int K, long batch, int mp) {      // (sized for the wide form's padding: enough for either)
+  const size_t b = (size_t)batch * geo_of(K, 0, mp, 0, 1).nlp_doubles() * sizeof(double) + 64;
   return (b + 255) & ~(size_t)255;
 }
 size_t persist_region1_offset(const int *levels, long batch, int mp) { return persist_ws_bytes(levels[0] - 1, batch, mp); }
-size_t persist_level_bytes_used(int K, long batch, int mp) { return (size_t)batch * geo_of(K, 0, mp).nlp_doubles() * sizeof(double); }
+size_t persist_level_bytes_used(int K, long batch, int mp) { return (size_t)batch * geo_of(K, 0, mp, 0, 1).nlp_doubles() * sizeof(double); }
 size_t persist_ws_bytes_nested(const int *levels, int nlev, long batch, int mp) {
   size_t b = persist_region1_offset(levels, batch, mp);
   if (nlev > 1) b += persist_ws_bytes(levels[1] - 1, batch, mp);
@@ -1613,6 +1637,13 @@ size_t persist_ws_bytes_nested(const int *levels, int nlev, long batch, int mp) 
 
 static void launch_solve(int scheme, int form, int mp, long batch, hipStream_t stream, const ascent_params *dp, const PGeo &g, double *w,
                          int max_iter, double tol) {
+  if (g.wide) {      // one NLP per wavefront
+    const dim3 gw((unsigned)batch), bw(WAVE);
+    if (mp) hipLaunchKernelGGL((p_solve<0, 0, 1, 0, 1>), gw, bw, 0, stream, dp, batch, g, w, max_iter, tol);
+    else if (scheme == 1) hipLaunchKernelGGL((p_solve<1, 0, 0, 0, 1>), gw, bw, 0, stream, dp, batch, g, w, max_iter, tol);
+    else hipLaunchKernelGGL((p_solve<0, 0, 0, 0, 1>), gw, bw, 0, stream, dp, batch, g, w, max_iter, tol);
+    return;
+  }
   const dim3 grid((unsigned)((batch + NPW - 1) / NPW)), block(WAVE);
   if (g.term == 2) {      // burnout anywhere on the ellipse (formulation 0)
     if (mp && scheme == 1) hipLaunchKernelGGL((p_solve<1, 0, 1, 2>), grid, block, 0, stream, dp, batch, g, w, max_iter, tol);
@@ -1637,21 +1668,22 @@ int persist_run_nested(const ascent_params *dp, long batch, int scheme, int form
                        double *dtf, int *dstatus, int *diters, double *dblob, hipStream_t stream, char *err, size_t errlen) {
   if (term == 2 && form != 0) { snprintf(err, errlen, "the persistent kernel carries terminal 2 for formulation 0 only"); return ASCENT_E_ARG; }
   double *region[2] = {ws, (double *)((char *)ws + persist_region1_offset(levels, batch, mp))};
-  PGeo g = geo_of(levels[nlev - 1] - 1, form, mp, term);
+  const int wide = use_wide(batch, scheme, form, mp, term);
+  PGeo g = geo_of(levels[nlev - 1] - 1, form, mp, term, wide);
   double *w = region[(nlev - 1) & 1];
   hipLaunchKernelGGL(p_init, dim3((unsigned)((g.Kp + WAVE - 1) / WAVE), (unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g, w, dguess,
                      warm, mu0, (const double *)nullptr, (const double *)nullptr, 0);
   for (int l = nlev - 1; l >= 0; l--) {
     launch_solve(scheme, form, mp, batch, stream, dp, g, w, max_iter, l == 0 ? tol : tol_coarse);
     if (l > 0) {
-      const PGeo gf = geo_of(levels[l - 1] - 1, form, mp, term);
+      const PGeo gf = geo_of(levels[l - 1] - 1, form, mp, term, wide);
       double *wf = region[(l - 1) & 1];
       hipLaunchKernelGGL(p_transfer, dim3((unsigned)((gf.Kp + WAVE - 1) / WAVE), (unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g,
                          (const double *)w, gf, wf, l == nlev - 1 ? mu_first : mu_next);
       g = gf; w = wf;
     }
   }
-  hipLaunchKernelGGL(p_finish, dim3((unsigned)g.nch, (unsigned)((batch + WAVE - 1) / WAVE)), dim3(WAVE, FIN_WAVES), 0, stream, dp, batch, g,
+  hipLaunchKernelGGL(p_finish, dim3((unsigned)((g.K + CH - 1) / CH), (unsigned)((batch + WAVE - 1) / WAVE)), dim3(WAVE, FIN_WAVES), 0, stream, dp, batch, g,
                      (const double *)w, dtraj, dtf, dstatus, diters, dblob);
   PCHK2(hipGetLastError());
   return ASCENT_OK;
@@ -1663,7 +1695,7 @@ int persist_run_nested(const ascent_params *dp, long batch, int scheme, int form
 int persist_probe(const ascent_params *dp, long batch, int scheme, int form, int mp, int term, int K, double *ws, const double *diterate, const double *dmu, const double *ddw,
                   double *dstep, int *dinertia, hipStream_t stream, char *err, size_t errlen) {
   if (term == 2 && form != 0) { snprintf(err, errlen, "the persistent kernel carries terminal 2 for formulation 0 only"); return ASCENT_E_ARG; }
-  const PGeo g = geo_of(K, form, mp, term);
+  const PGeo g = geo_of(K, form, mp, term, use_wide(batch, scheme, form, mp, term));
   const dim3 ng((unsigned)((g.Kp + WAVE - 1) / WAVE), (unsigned)batch);
   hipLaunchKernelGGL(p_init, ng, dim3(WAVE), 0, stream, dp, batch, g, ws, diterate, 2, 0.1, dmu, ddw, 1);
   launch_solve(scheme, form, mp, batch, stream, dp, g, ws, 1000, -1.0);
@@ -1677,7 +1709,7 @@ int persist_probe(const ascent_params *dp, long batch, int scheme, int form, int
 // (mu and delta_w do not enter the rows).
 int persist_probe_rows(const ascent_params *dp, long batch, int scheme, int form, int K, double *ws, const double *diterate, const double *dzero,
                        double *ddefects, double *djac, double *dhess, hipStream_t stream, char *err, size_t errlen) {
-  const PGeo g = geo_of(K, form, 0);
+  const PGeo g = geo_of(K, form, 0, 0, use_wide(batch, scheme, form, 0, 0));
   const dim3 ng((unsigned)((g.Kp + WAVE - 1) / WAVE), (unsigned)batch);
   hipLaunchKernelGGL(p_init, ng, dim3(WAVE), 0, stream, dp, batch, g, ws, diterate, 2, 0.1, dzero, dzero, 2);
   launch_solve(scheme, form, 0, batch, stream, dp, g, ws, 1000, -1.0);

@@ -83,9 +83,16 @@ def test_argument_validation(lib):
     o4 = _lib.AscentOptsC(n_nodes=200, scheme=0, max_iter=10, warm_start=0, tol=1e-8, mu_init=0.0, move_penalty=2)
     rc = lib.ascent_solve_batch(P.ctypes.data_as(C.c_void_p), 1, C.byref(o4), None, None, None, None, None, None, 0, None, 0)
     assert rc == -1 and b"move_penalty" in lib.ascent_strerror(rc)
-    o5 = _lib.AscentOptsC(n_nodes=200, scheme=0, max_iter=10, warm_start=0, tol=1e-8, mu_init=0.0, move_penalty=1, formulation=1)
+    # (the move penalty with the v1 formulation lives in the persistent kernel only; terminal 2 has the current formulation only)
+    o5 = _lib.AscentOptsC(n_nodes=200, scheme=0, max_iter=10, warm_start=0, tol=1e-8, mu_init=0.0, move_penalty=1, formulation=1, solver_path=4)
     rc = lib.ascent_solve_batch(P.ctypes.data_as(C.c_void_p), 1, C.byref(o5), None, None, None, None, None, None, 0, None, 0)
     assert rc == -1 and b"formulation 0" in lib.ascent_strerror(rc)
+    o6 = _lib.AscentOptsC(n_nodes=200, scheme=0, max_iter=10, warm_start=0, tol=1e-8, mu_init=0.0, terminal=2, formulation=1)
+    rc = lib.ascent_solve_batch(P.ctypes.data_as(C.c_void_p), 1, C.byref(o6), None, None, None, None, None, None, 0, None, 0)
+    assert rc == -1 and b"terminal 2" in lib.ascent_strerror(rc)
+    o7 = _lib.AscentOptsC(n_nodes=200, scheme=0, max_iter=10, warm_start=0, tol=1e-8, mu_init=0.0, terminal=3)
+    rc = lib.ascent_solve_batch(P.ctypes.data_as(C.c_void_p), 1, C.byref(o7), None, None, None, None, None, None, 0, None, 0)
+    assert rc == -1 and b"terminal" in lib.ascent_strerror(rc)
 
 
 def test_product_does_not_import_oracle():
