@@ -1612,11 +1612,12 @@ static PGeo geo_of(int K, int form = 0, int mp = 0, int term = 0, int wide = 0) 
   g.K = K; g.nch = (K + ch - 1) / ch; g.Kp = g.nch * ch; g.form = form; g.mp = mp ? 1 : 0; g.term = term == 2 ? 2 : 0; g.wide = wide ? 1 : 0;
   return g;
 }
-// Batches that cannot give every SIMD a wavefront of four NLPs (MI355X: 256 CUs x 4 SIMDs) run one NLP per wavefront; the v1
-// formulation, the trapezoid with the move penalty and terminal 2 keep the four-NLP form (fewer instantiations of a large kernel).
+// Batches that cannot give every SIMD a wavefront of four NLPs (MI355X: 256 CUs x 4 SIMDs) run one NLP per wavefront; the
+// trapezoid with the move penalty and terminal 2 keep the four-NLP form (fewer instantiations of a large kernel).
 static int use_wide(long batch, int scheme, int form, int mp, int term) {
-  if (const char *e = getenv("ASCENT_PERSIST_WIDE")) return e[0] == '1' && form == 0 && term == 0 && !(scheme == 1 && mp);
-  return batch <= 1024 && form == 0 && term == 0 && !(scheme == 1 && mp);
+  const bool have = term == 0 && !(scheme == 1 && mp);
+  if (const char *e = getenv("ASCENT_PERSIST_WIDE")) return e[0] == '1' && have;
+  return batch <= 1024 && have;
 }
 
 // One grid level's workspace, rounded up to a multiple of 256 bytes: the two regions of the nested iteration are laid out
@@ -1639,7 +1640,9 @@ static void launch_solve(int scheme, int form, int mp, long batch, hipStream_t s
                          int max_iter, double tol) {
   if (g.wide) {      // one NLP per wavefront
     const dim3 gw((unsigned)batch), bw(WAVE);
-    if (mp) hipLaunchKernelGGL((p_solve<0, 0, 1, 0, 1>), gw, bw, 0, stream, dp, batch, g, w, max_iter, tol);
+    if (mp && form == 1) hipLaunchKernelGGL((p_solve<0, 1, 1, 0, 1>), gw, bw, 0, stream, dp, batch, g, w, max_iter, tol);
+    else if (form == 1) hipLaunchKernelGGL((p_solve<0, 1, 0, 0, 1>), gw, bw, 0, stream, dp, batch, g, w, max_iter, tol);
+    else if (mp) hipLaunchKernelGGL((p_solve<0, 0, 1, 0, 1>), gw, bw, 0, stream, dp, batch, g, w, max_iter, tol);
     else if (scheme == 1) hipLaunchKernelGGL((p_solve<1, 0, 0, 0, 1>), gw, bw, 0, stream, dp, batch, g, w, max_iter, tol);
     else hipLaunchKernelGGL((p_solve<0, 0, 0, 0, 1>), gw, bw, 0, stream, dp, batch, g, w, max_iter, tol);
     return;

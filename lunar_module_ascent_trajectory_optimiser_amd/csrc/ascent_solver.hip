@@ -934,17 +934,17 @@ bool use_dense_path(const ascent_opts *o, int64_t batch) {
   // (the move penalty and terminal 2 exist in the persistent kernel and in the dense-block path: an override that names any other family means the dense one)
   if ((o->move_penalty || o->terminal == 2) && o->formulation == 0 && ((e && strcmp(e, "persist")) || getenv("ASCENT_FACTOR"))) return true;
   if (e) return !strcmp(e, "dense") && o->formulation == 0;
-  // A handful of NLPs cannot fill the hand-tuned kernels (one wavefront per four NLPs, serial over the nodes: 2.8 ms at
-  // N=200, 7.3 ms at N=600, 25-31 ms at N=2000 for up to 8 NLPs); the dense-block path with its Newton systems solved by
-  // cyclic reduction over the nodes spreads ONE NLP over hundreds of wavefronts and costs ~1 us per node and NLP on top of
-  // a start-up that grows with log N: 3.4 ms (N=200), 4.4 ms (N=600), 8.6 ms (N=2000) for a single NLP; 4.4 / 8.6 / 24 ms
-  // for eight (scripts/small_batch_paths.py).  Taken on grids of >= 400 intervals while batch <= min(8, intervals/75).
+  // A handful of NLPs cannot fill the hand-tuned kernels (one wavefront per NLP, serial over the nodes: 2.0 ms at N=200,
+  // 4.8 ms at N=600, 17 ms at N=2000 for one NLP; 2.1 / 6.0 / 21.5 ms for eight); the dense-block path with its Newton systems
+  // solved by cyclic reduction over the nodes spreads ONE NLP over hundreds of wavefronts and costs ~1 us per node and NLP on
+  // top of a start-up that grows with log N: 3.5 ms (N=200), 4.4 ms (N=600), 8.5 ms (N=2000) for a single NLP; 4.5 / 8.6 /
+  // 23 ms for eight (scripts/small_batch_paths.py, round 3).  Taken on grids of >= 400 intervals while batch <= min(6, intervals/300).
   // ASCENT_SMALL_BATCH=off keeps the hand-tuned path.
   const char *sb = getenv("ASCENT_SMALL_BATCH");
   if (sb && !strcmp(sb, "off")) return false;
   if (o->formulation != 0 || getenv("ASCENT_FACTOR")) return false;
   const int64_t K = (int64_t)o->n_nodes - 1;
-  const int64_t lim = K < 400 ? 0 : (K / 75 < 8 ? K / 75 : 8);
+  const int64_t lim = K < 400 ? 0 : (K / 300 < 6 ? K / 300 : 6);
   return batch <= lim;
 }
 

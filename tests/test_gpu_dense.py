@@ -318,7 +318,7 @@ def test_pcr_newton_variant_and_small_batch_dispatch(coracle, monkeypatch):
                 continue
             res[name] = A.solve_batch(P, ntf, tol=1e-9, scheme=scheme, max_iter=500, path="dense" if name in ("pcr", "riccati") else "auto")
             assert np.all(res[name].status == 0)
-        auto_is_pcr = scheme == 2 or B <= (0 if ntf - 1 < 400 else min(8, (ntf - 1) // 75))     # the dispatch rule (ascent_solver.hip)
+        auto_is_pcr = scheme == 2 or B <= (0 if ntf - 1 < 400 else min(6, (ntf - 1) // 300))     # the dispatch rule (ascent_solver.hip)
         monkeypatch.delenv("ASCENT_SMALL_BATCH", raising=False)
         assert A.default_path(B, ntf, scheme=scheme) == ("dense" if auto_is_pcr else "persist")
         for name in res:
