@@ -1135,7 +1135,7 @@ int ascent_debug_profile(unsigned long long *out8, int reset) {
 }
 #endif
 
-int ascent_version(void) { return 210; }
+int ascent_version(void) { return 300; }
 
 int ascent_device_count(void) {
   int n = 0;
