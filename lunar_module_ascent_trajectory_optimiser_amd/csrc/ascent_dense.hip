@@ -1000,9 +1000,14 @@ __global__ __launch_bounds__(WAVE) void pc_assemble(const ascent_params *params,
     const double is1 = rcp(s.s1), is2 = rcp(s.s2);
     const double sig1 = s.zs1 * is1 + dw, sig2 = s.zs2 * is2 + dw, rs1 = -mu * is1 - s.nu1, rs2 = -mu * is2 - s.nu2;
     const double w1 = s.nu1 + sig1 * (tm.g1 - s.s1) + rs1, w2 = s.nu2 + sig2 * (tm.g2 - s.s2) + rs2;
-    terminal_hessian(QT, tm, s.nu3, s.nu1, s.nu2, sig1, sig2);
-    rt4[0] = s.nu3 * tm.e3g[0] + w1 * tm.g1g[0]; rt4[1] = s.nu3 * tm.e3g[1] + w1 * tm.g1g[1];
-    rt4[2] = s.nu3 * tm.e3g[2] + w2 * tm.g2g[0]; rt4[3] = s.nu3 * tm.e3g[3] + w2 * tm.g2g[1];
+    if (d.term == 2) {      // burnout anywhere on the ellipse: the generalised terminal block; no r.v = 0 (e3g stays zero)
+      terminal_hessian_any(QT, tm, s.nu1, s.nu2, sig1, sig2);
+      terminal_grad_any(tm, w1, w2, rt4);
+    } else {
+      terminal_hessian(QT, tm, s.nu3, s.nu1, s.nu2, sig1, sig2);
+      rt4[0] = s.nu3 * tm.e3g[0] + w1 * tm.g1g[0]; rt4[1] = s.nu3 * tm.e3g[1] + w1 * tm.g1g[1];
+      rt4[2] = s.nu3 * tm.e3g[2] + w2 * tm.g2g[0]; rt4[3] = s.nu3 * tm.e3g[3] + w2 * tm.g2g[1];
+    }
     ASC_UNROLL
     for (int q = 0; q < 4; q++) e3g[q] = tm.e3g[q];
   }
@@ -1165,6 +1170,7 @@ __global__ __launch_bounds__(WAVE) void pc_step(const ascent_params *params, lon
   s11 += s.zlt * itl + s.zut * itu + dw + hth;
   t1 += -(rth + mu * (itu - itl));
   t2 += -tm.e3;
+  if (d.term == 2) s22 = -1.0;                  // (no r.v = 0 row: its border column is zero; a unit pivot closes nu3, d nu3 = 0)
   const double det = s11 * s22 - s12 * s21;
   const double dth = (t1 * s22 - s12 * t2) / det, dnu3 = (s11 * t2 - s21 * t1) / det;
   int ok = isfinite(dth) && isfinite(dnu3) && !flags[p];
@@ -1234,6 +1240,10 @@ __global__ __launch_bounds__(WAVE) void pc_step(const ascent_params *params, lon
   ds.th = dth; ds.nu3 = dnu3;
   ds.s1 = (tm.g1 - s.s1) + tm.g1g[0] * dzKx + tm.g1g[1] * dzKy;
   ds.s2 = (tm.g2 - s.s2) + tm.g2g[0] * dzKvx + tm.g2g[1] * dzKvy;
+  if (d.term == 2) {
+    ds.s1 += tm.g1v[0] * dzKvx + tm.g1v[1] * dzKvy;
+    ds.s2 += tm.g2p[0] * dzKx + tm.g2p[1] * dzKy;
+  }
   ds.nu1 = sig1 * ds.s1 + rs1;
   ds.nu2 = sig2 * ds.s2 + rs2;
   ds.zs1 = mu / s.s1 - s.zs1 - s.zs1 / s.s1 * ds.s1;

@@ -1184,7 +1184,10 @@ int ascent_solve_batch(const ascent_params *p, int64_t batch, const ascent_opts 
   const size_t rows = 21 * (size_t)K + NSC;
   const int lpt = lanes_per_tile(batch);
   const bool dense = use_dense_path(o, batch);
-  const bool pcr = dense && o->terminal != 2 && use_pcr_newton(batch, o->move_penalty != 0);     // (terminal 2: the Riccati form carries it)
+  // (terminal 2: the Riccati form.  Its two conditions are nearly dependent near the periapsis -- multipliers of -3 and -3000 -- and the
+  //  cyclic-reduction variant's curvature test, which sees no inertia, then picks regularisations that stall: 45-99 iterations on a
+  //  sweep against 31-48, max_iter on the nominal Hermite-Simpson problem; measured in round 3, the PCR kernels do carry the block)
+  const bool pcr = dense && o->terminal != 2 && use_pcr_newton(batch, o->move_penalty != 0);
   const bool persist = !dense && use_persist_path(o, batch);
   const bool split = o->scheme == 1 || o->formulation == 1 || use_split_pipeline(batch);
   if ((o->move_penalty || o->terminal == 2) && !persist && !dense) { snprintf(g_err, sizeof g_err, "move_penalty / terminal 2 exist in the persistent kernel and the dense-block path only (ASCENT_PIPELINE / ASCENT_FACTOR name another family)"); return ASCENT_E_ARG; }
@@ -1401,7 +1404,7 @@ int ascent_kkt_step_path(const ascent_params *p, int64_t batch, const ascent_opt
   const int K = o->n_nodes - 1;
   const size_t rows = 21 * (size_t)K + NSC;
   const int lpt = lanes_per_tile(batch);
-  const bool pcr_probe = path == ASCENT_PATH_DENSE && o->terminal != 2 && use_pcr_newton(batch, o->move_penalty != 0);
+  const bool pcr_probe = path == ASCENT_PATH_DENSE && (o->terminal != 2 || getenv("ASCENT_DENSE_NEWTON")) && use_pcr_newton(batch, o->move_penalty != 0);
   if (o->terminal == 2 && path != ASCENT_PATH_DENSE && path != ASCENT_PATH_PERSIST) { snprintf(g_err, sizeof g_err, "terminal 2 exists in the persistent kernel and in the dense-block path only"); return ASCENT_E_ARG; }
   rc = ensure_ws(g_ws_slot0(device_id), path == ASCENT_PATH_DENSE ? (pcr_probe ? dense_pcr_ws_bytes(K, (long)batch) : dense_ws_bytes(K, (long)batch))
                             : path == ASCENT_PATH_PERSIST ? persist_ws_bytes(K, (long)batch, (int)o->move_penalty) : path == ASCENT_PATH_FUSED ? ws_bytes(K, batch, lpt) : pipeline_ws_bytes(K, (long)batch));

@@ -255,8 +255,13 @@ def test_kkt_step_with_terminal2_persistent_kernel_equals_dense_path(coracle, mo
     sd, idn = A.kkt_step(S, blobs, mu, dw, nt, path="dense", scheme=scheme, terminal=2, move_penalty=mp)
     s0, _ = A.kkt_step(S, blobs, mu, dw, nt, path="persist", scheme=scheme, terminal=1, move_penalty=mp)
     assert np.array_equal(ip, idn) and (ip == 0).sum() >= 3
+    monkeypatch.setenv("ASCENT_DENSE_NEWTON", "pcr")             # ... and the dense path's cyclic-reduction variant (no inertia information)
+    sc_, ic_ = A.kkt_step(S, blobs, mu, dw, nt, path="dense", scheme=scheme, terminal=2, move_penalty=mp)
+    assert ((ip == 0) & (ic_ == 0)).sum() >= 2
     for b in np.flatnonzero(ip == 0):
         assert np.abs(sp[:, b] - sd[:, b]).max() <= 1e-9 * max(1.0, np.abs(sd[:, b]).max())
+        if ic_[b] == 0:      # (its curvature test may refuse a step the exact-inertia forms take)
+            assert np.abs(sc_[:, b] - sd[:, b]).max() <= 1e-8 * max(1.0, np.abs(sd[:, b]).max())
         assert np.abs(sp[:, b] - s0[:, b]).max() > 1e-6          # (another terminal block: another step)
 
 
