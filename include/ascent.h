@@ -82,12 +82,14 @@ typedef struct ascent_opts {
                                Dense-block path (any scheme, formulation 0)                                   */
   int32_t solver_path;  /* 0 = automatic (hand-tuned sparse kernels for schemes 0/1, dense-block path for scheme 2);
                            ASCENT_PATH_DENSE = the dense-block path for any scheme (formulation 0 only)       */
-  int32_t move_penalty; /* 0 = ascent_params.dcost is ignored (the default: the penalty moves the reference's t_f by 3.5e-6
-                               relative);
-                           1 = :99 angledoubledot.DCOST applied: the objective is tf + dcost * sum_k |u_k - u_{k-1}|
-                               (u_{-1} = 0, the MV's initial value; an l1 term with a slack pair per step, as APMonitor
-                               documents DCOST).  Any scheme, formulation 0; carried by the dense-block path (the control
-                               becomes the eighth state of a stage)                                                 */
+  int32_t move_penalty; /* 0 = ascent_params.dcost is ignored (a sweep's parameter sets may carry none);
+                           1 = :99 angledoubledot.DCOST applied -- the model the reference declares: the objective is
+                               tf + dcost * sum_k |u_k - u_{k-1}| (u_{-1} = 0, the MV's initial value; an l1 term with a slack pair
+                               per step, as APMonitor documents DCOST).  Schemes 0 / 1: inside the persistent kernel (the control
+                               becomes the eighth state of a stage, the pair reduces to one pivot); scheme 2: dense-block path.
+                               With formulation 1 (the v1 script's angle.DCOST, PDF p26; scheme 0): the penalty is on the angle,
+                               i.e. weight dcost * angle_ub / 2 on the normalised control, which starts from -1 (angle 0).
+                               Needs dcost > 0 for every problem                                                     */
   int32_t reserved;     /* 0 */
 } ascent_opts;
 
@@ -135,8 +137,8 @@ const char *ascent_strerror(int code);
  * [21K+10][batch] receives the full primal-dual solution (usable as a warm start).
  * stream: hipStream_t or NULL.  With host pointers the call returns after the results are in the
  * caller's buffers.  With ptr_is_device != 0 and a stream, the persistent kernel (schemes 0 and 1, both
- * formulations: the default at every batch size; ascent_default_path) is only enqueued -- a handful of launches per grid level, no
- * host involvement; the split pipeline (ASCENT_PIPELINE=split) and the dense-block path (scheme 2, a few NLPs
+ * formulations, with or without the move penalty, every terminal mode: the default at every batch size; ascent_default_path) is
+ * only enqueued -- a handful of launches per grid level, no host involvement (with the NULL stream the call waits for the solve); the split pipeline (ASCENT_PIPELINE=split) and the dense-block path (scheme 2, a few NLPs
  * on long grids) synchronise the stream once per burst of interior-point rounds, because the host steers the
  * rounds, and return with the last kernels enqueued.
  * Concurrency: host-side, calls on one device are serialised by a mutex.  Device-side, the library keeps a workspace per

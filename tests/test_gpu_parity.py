@@ -716,6 +716,12 @@ def test_config4_whole_box_on_one_gpu(coracle):
     idx = np.linspace(0, len(full) - 1, 48).astype(int)
     ref = coracle.solve_batch(full[idx], NT, 300, 1e-9)
     assert np.array_equal(r.iters[idx], ref["iters"]) and np.abs(r.tf[idx] - ref["tf"]).max() <= 1e-12
+    # the same box of the model the reference declares -- with its MV DCOST as the l1 move penalty (Launch_Optimiser.py:99)
+    full[:, 15] = 1e-5
+    rd = A.solve_batch(full, NT, tol=1e-9, want_traj=False, move_penalty=True)
+    assert np.all(rd.status == 0) and rd.iters.max() <= 32 and np.all(rd.tf > r.tf) and np.all(rd.tf - r.tf < 1e-4)
+    refd = coracle.solve_batch(full[idx], NT, 300, 1e-9, move_penalty=True)
+    assert np.abs(rd.iters[idx].astype(int) - refd["iters"]).max() <= 1 and np.abs(rd.tf[idx] - refd["tf"]).max() <= 1e-9
 
 
 def test_persistent_kernel_trapezoid_matches_split_pipeline_and_oracle(coracle, monkeypatch):
