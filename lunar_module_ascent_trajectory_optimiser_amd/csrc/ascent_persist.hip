@@ -38,108 +38,12 @@
 #include "ascent_device.hpp"
 #include "ascent_tile.hpp"
 #include "ascent_persist.hpp"
+#include "ascent_persist_dev.hpp"
 
 using namespace ascent;
 
 namespace {
 
-constexpr int NPW = 4, CH = 16;                 // NLPs per wavefront, nodes per chunk
-constexpr int O_Z = 0, O_U = 7, O_L = 8, O_ZB = 15;
-constexpr int O_LU = 21, O_PP = 22, O_PN = 23, O_ZP = 24, O_ZN = 25;      // move penalty only: lambda_u, p, n, z_p, z_n
-// Rows of an NLP's node arrays: two iterate buffers, the step, the feedback gains of the factorisation.  MP = 1: with the l1 move
-// penalty (ascent_opts.move_penalty, the reference's angledoubledot.DCOST, Launch_Optimiser.py:99) the control is the eighth
-// state of a stage and an iterate carries five more rows per node.
-template <int MP>
-struct Lay {
-  static constexpr int NS = 7 + MP, NIT = 21 + 5 * MP;
-  static constexpr int R_IT = 0, R_ST = 2 * NIT, R_KA = 3 * NIT, R_K0 = R_KA + NS, NROWS = R_K0 + 3;
-  // LDS stage rows (one chunk): blocks of the factorisation; the forward / adjoint phases reuse the area
-  // (MP: the mass row of hT F is a constant of the NLP and the barrier gradients are folded into rz, so that the stage stays within
-  //  56 rows -- with 12 output rows and the small arrays 40 672 bytes per wavefront: four wavefronts per CU, as without the penalty)
-  static constexpr int S_G = 0, S_E = 8, S_H = 12, S_F = 22, S_C = S_F + 7 - MP, S_RZ = S_C + NS, S_GT = S_RZ + NS, S_SC = S_GT + NS;
-  static constexpr int S_ROWS = MP ? 56 : 55;        // (MP: S_SC + 3 = 55 in the factor phase; the forward phase's 7 lanes x 8 rows)
-  static constexpr int OUT_ROWS = 11 + MP;
-  static_assert(S_SC + (MP ? 3 : 5) <= S_ROWS, "stage rows");
-};
-constexpr int R_IT = 0;
-constexpr int LDW = 65;                         // row stride in doubles: odd, so that the 16 rows a sweep step gathers hit 16 banks
-enum {
-  X_STATE, X_ITERS, X_STATUS, X_CUR, X_FIRST, X_LS, X_MU, X_NUP, X_DW, X_DWL, X_ALPHA, X_ADU, X_PHI0, X_DM, X_C1, X_SL,
-  X_RTH, X_DTH, X_DNU3, X_SIG1, X_SIG2, X_RS1, X_RS2, X_CG1, X_CG2,
-  X_ITB,                     // iterations spent on the coarser grids of the nested iteration
-  X_PROBE, X_PDW,            // parity probe: one round at the caller's iterate, mu and delta_w, then stop (1: Newton step; 2: the node rows of the factor phase)
-  X_TEVAL,                   // the trial point of the next round has been evaluated already (by the adjoint phase)
-  X_P,                       // 10 reduced partials of that trial point: rd cinf pmin pmax l1 zsum rth c1 sl mv
-  X_PEND = X_P + 9,
-  X_MV,                      // move penalty: sum of the slack pairs of the iterate (its part of the objective, without the weight)
-  X_S,                       // 10 scalars of the iterate
-  X_D = X_S + 10,            // 10 step scalars
-  NSCAL = X_D + 10
-};
-enum { ST_TRIAL = 0, ST_FACTOR = 1, ST_FACTORED = 2, ST_DONE = 3 };
-
-struct PGeo {
-  int K, Kp, nch, form, mp, term, wide;      // wide: one NLP per wavefront, 64-node chunks; term: ascent_opts.terminal 2 (burnout anywhere on the ellipse) or 0
-  __host__ __device__ int nit() const { return mp ? Lay<1>::NIT : Lay<0>::NIT; }
-  __host__ __device__ int r_st() const { return 2 * nit(); }
-  __host__ __device__ int nrows() const { return mp ? Lay<1>::NROWS : Lay<0>::NROWS; }
-  __host__ __device__ size_t nlp_doubles() const { return (size_t)nrows() * Kp + NSCAL; }
-};
-
-template <int SRC>
-ASC_DEV double bcast16(double v) {
-  const long x = __builtin_amdgcn_mov_dpp(__builtin_bit_cast(long, v), 0x150 + SRC, 0xf, 0xf, false);
-  return __builtin_bit_cast(double, x);
-}
-template <int N>
-struct OneHot {
-  double m[N];
-  ASC_DEV explicit OneHot(int role) {
-    ASC_UNROLL
-    for (int i = 0; i < N; i++) m[i] = (role == i || (i == 0 && role >= N)) ? 1.0 : 0.0;
-  }
-  ASC_DEV double pick(const double *v) const {
-    double r = m[0] * v[0];
-    ASC_UNROLL
-    for (int i = 1; i < N; i++) r += m[i] * v[i];
-    return r;
-  }
-};
-ASC_DEV void wsync() {
-  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-  __builtin_amdgcn_wave_barrier();
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-}
-// reductions over the 16 lanes of an NLP (xor strides stay inside the row of 16)
-ASC_DEV double gsum16(double v) { v += __shfl_xor(v, 1); v += __shfl_xor(v, 2); v += __shfl_xor(v, 4); v += __shfl_xor(v, 8); return v; }
-ASC_DEV double gmax16(double v) { v = fmax(v, __shfl_xor(v, 1)); v = fmax(v, __shfl_xor(v, 2)); v = fmax(v, __shfl_xor(v, 4)); return fmax(v, __shfl_xor(v, 8)); }
-ASC_DEV double gmin16(double v) { v = fmin(v, __shfl_xor(v, 1)); v = fmin(v, __shfl_xor(v, 2)); v = fmin(v, __shfl_xor(v, 4)); return fmin(v, __shfl_xor(v, 8)); }
-// ... or over the whole wavefront (WIDE: one NLP per wavefront)
-template <int WIDE> ASC_DEV double gsumW(double v) { v = gsum16(v); if constexpr (WIDE) { v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); } return v; }
-template <int WIDE> ASC_DEV double gmaxW(double v) { v = gmax16(v); if constexpr (WIDE) { v = fmax(v, __shfl_xor(v, 16)); v = fmax(v, __shfl_xor(v, 32)); } return v; }
-template <int WIDE> ASC_DEV double gminW(double v) { v = gmin16(v); if constexpr (WIDE) { v = fmin(v, __shfl_xor(v, 16)); v = fmin(v, __shfl_xor(v, 32)); } return v; }
-
-ASC_DEV Scal lds_scal(const double *sc, int r0) {
-  Scal s;
-  s.th = sc[r0 + S_TH]; s.zlt = sc[r0 + S_ZLT]; s.zut = sc[r0 + S_ZUT]; s.s1 = sc[r0 + S_S1]; s.s2 = sc[r0 + S_S2];
-  s.zs1 = sc[r0 + S_ZS1]; s.zs2 = sc[r0 + S_ZS2]; s.nu3 = sc[r0 + S_NU3]; s.nu1 = sc[r0 + S_NU1]; s.nu2 = sc[r0 + S_NU2];
-  return s;
-}
-ASC_DEV void put_scal(double *sc, int r0, const Scal &s) {
-  sc[r0 + S_TH] = s.th; sc[r0 + S_ZLT] = s.zlt; sc[r0 + S_ZUT] = s.zut; sc[r0 + S_S1] = s.s1; sc[r0 + S_S2] = s.s2;
-  sc[r0 + S_ZS1] = s.zs1; sc[r0 + S_ZS2] = s.zs2; sc[r0 + S_NU3] = s.nu3; sc[r0 + S_NU1] = s.nu1; sc[r0 + S_NU2] = s.nu2;
-}
-ASC_DEV Scal trial_scal(const Der &d, const Scal &s, const Scal &ds, double alpha, double adu, double mu, bool first) {
-  Scal t = s;
-  if (first) return t;
-  t.th += alpha * ds.th; t.s1 += alpha * ds.s1; t.s2 += alpha * ds.s2;
-  t.nu3 += alpha * ds.nu3; t.nu1 += alpha * ds.nu1; t.nu2 += alpha * ds.nu2;
-  t.zlt = clipz(s.zlt + adu * ds.zlt, t.th - d.tlb, mu);
-  t.zut = clipz(s.zut + adu * ds.zut, d.tub - t.th, mu);
-  t.zs1 = clipz(s.zs1 + adu * ds.zs1, t.s1, mu);
-  t.zs2 = clipz(s.zs2 + adu * ds.zs2, t.s2, mu);
-  return t;
-}
 
 // ==============================================================================================================
 // p_init / p_transfer / p_finish: starting points and results.  Lane = (NLP, node) in p_init and p_transfer.
@@ -437,31 +341,6 @@ __global__ __launch_bounds__(WAVE) void p_probe_rows_out(const ascent_params *pa
 // ==============================================================================================================
 // p_solve: the whole interior-point loop of one grid level
 // ==============================================================================================================
-struct NodeIn {      // what a node evaluation reads: node k of the iterate, the state of node k-1, the multipliers of node k+1
-  double z[7], zp[7], l[7], ln[7], zb[6], u;
-  double up, lu, lun, pp, pn, zpp, zpn;      // move penalty only: u_{k-1}, lambda_u of nodes k and k+1, the slack pair and its multipliers
-};
-// (uinit: the control "before node 0" of the movement equations -- the MV's initial value: 0, or -1 where the v1 formulation's
-//  angle starts at 0; loads of a STEP pass 0)
-template <int MP = 0>
-ASC_DEV void load_node(const double *it, int Kp, int K, int k, NodeIn &n, double uinit = 0.0) {
-  ASC_UNROLL
-  for (int i = 0; i < 7; i++) {
-    n.z[i] = it[(O_Z + i) * Kp + k];
-    n.l[i] = it[(O_L + i) * Kp + k];
-    n.zp[i] = k > 0 ? it[(O_Z + i) * Kp + k - 1] : 0.0;
-    n.ln[i] = k + 1 < K ? it[(O_L + i) * Kp + k + 1] : 0.0;
-  }
-  n.u = it[O_U * Kp + k];
-  ASC_UNROLL
-  for (int b = 0; b < 6; b++) n.zb[b] = it[(O_ZB + b) * Kp + k];
-  if constexpr (MP) {
-    n.up = k > 0 ? it[O_U * Kp + k - 1] : uinit;
-    n.lu = it[O_LU * Kp + k];
-    n.lun = k + 1 < K ? it[O_LU * Kp + k + 1] : 0.0;
-    n.pp = it[O_PP * Kp + k]; n.pn = it[O_PN * Kp + k]; n.zpp = it[O_ZP * Kp + k]; n.zpn = it[O_ZN * Kp + k];
-  }
-}
 
 // Rows xdot and ydot of A^-1, A = I - dt df/dz (see solveA in ascent_device.hpp).  The other rows follow from them:
 // row x = e_x + dt row xdot, row y = e_y + dt row ydot, row angle = e_angle + dt e_angledot; rows angledot and mass are unit vectors.
@@ -474,28 +353,6 @@ ASC_DEV void ainv_vrows(const double *G, const double *E, double dt, double *rvx
   for (int i = 0; i < 7; i++) { rvx[i] = E[0] * c1[i] + E[1] * c2[i]; rvy[i] = E[2] * c1[i] + E[3] * c2[i]; }
 }
 
-// Partial sums of the merit function and the KKT error over the nodes a lane evaluates
-struct Part {
-  double rd, cinf, pmin, pmax, l1, zsum, rth, c1, sl, mv;
-  ASC_DEV void clear() { rd = 0.0; cinf = 0.0; pmin = 1e300; pmax = -1e300; l1 = 0.0; zsum = 0.0; rth = 0.0; c1 = 0.0; sl = 0.0; mv = 0.0; }
-  template <int MP = 0>
-  ASC_DEV void reduce16() {
-    rd = gmax16(rd); cinf = gmax16(cinf); pmin = gmin16(pmin); pmax = gmax16(pmax);
-    l1 = gsum16(l1); zsum = gsum16(zsum); rth = gsum16(rth); c1 = gsum16(c1); sl = gsum16(sl);
-    if constexpr (MP) mv = gsum16(mv);
-  }
-  template <int MP, int WIDE>
-  ASC_DEV void reduceW() {
-    rd = gmaxW<WIDE>(rd); cinf = gmaxW<WIDE>(cinf); pmin = gminW<WIDE>(pmin); pmax = gmaxW<WIDE>(pmax);
-    l1 = gsumW<WIDE>(l1); zsum = gsumW<WIDE>(zsum); rth = gsumW<WIDE>(rth); c1 = gsumW<WIDE>(c1); sl = gsumW<WIDE>(sl);
-    if constexpr (MP) mv = gsumW<WIDE>(mv);
-  }
-};
-struct TrialCtx {       // what the trial point of an NLP needs besides the node data
-  double alpha, adu, mlo, mhi, dt, be, hT, dcw;
-  bool first;
-  Scal stt;
-};
 
 // The trial point x + alpha dx at node k (iterate n, step dn), stored into the other iterate buffer, and its pieces of the
 // l1 merit function and of the KKT error (Launch_Optimiser.py:114-136 evaluated once, with first derivatives) -- in two parts:
@@ -1605,29 +1462,40 @@ __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, lon
 
 namespace ascent {
 
-// wide: one NLP per wavefront, 64-node chunks (node arrays padded to a multiple of 64); otherwise four NLPs per wavefront, 16-node chunks
-static PGeo geo_of(int K, int form = 0, int mp = 0, int term = 0, int wide = 0) {
+// wide: one NLP per wavefront, 64-node chunks (node arrays padded to a multiple of 64); otherwise four NLPs per wavefront, 16-node chunks.
+// scheme 2 (Hermite-Simpson, ascent_hs.hip): chunks of 48 / 12 nodes.
+static PGeo geo_of(int K, int form = 0, int mp = 0, int term = 0, int wide = 0, int scheme = 0) {
   PGeo g;
-  const int ch = wide ? 64 : CH;
+  const int ch = scheme == 2 ? hs_chunk_nodes(wide) : wide ? 64 : CH;
   g.K = K; g.nch = (K + ch - 1) / ch; g.Kp = g.nch * ch; g.form = form; g.mp = mp ? 1 : 0; g.term = term == 2 ? 2 : 0; g.wide = wide ? 1 : 0;
   return g;
 }
 // Batches that cannot give every SIMD a wavefront of four NLPs (MI355X: 256 CUs x 4 SIMDs) run one NLP per wavefront; the
 // trapezoid with the move penalty and terminal 2 keep the four-NLP form (fewer instantiations of a large kernel).
 static int use_wide(long batch, int scheme, int form, int mp, int term) {
-  const bool have = term == 0 && !(scheme == 1 && mp);
+  const bool have = scheme == 2 ? true : term == 0 && !(scheme == 1 && mp);
   if (const char *e = getenv("ASCENT_PERSIST_WIDE")) return e[0] == '1' && have;
   return batch <= 1024 && have;
 }
 
 // One grid level's workspace, rounded up to a multiple of 256 bytes: the two regions of the nested iteration are laid out
 // back to back with exactly these sizes (persist_region1_offset below is the one place that says where the second one starts).
-size_t persist_ws_bytes(int K, long batch, int mp) {      // (sized for the wide form's padding: enough for either)
-  const size_t b = (size_t)batch * geo_of(K, 0, mp, 0, 1).nlp_doubles() * sizeof(double) + 64;
+// Sized for the largest padding of the node arrays any kernel form uses (chunks of 64, 48, 16 or 12 nodes): enough for each.
+static size_t level_doubles(int K, int mp) {
+  size_t m = 0;
+  for (int scheme = 0; scheme <= 2; scheme += 2)
+    for (int wide = 0; wide <= 1; wide++) {
+      const size_t n = geo_of(K, 0, mp, 0, wide, scheme).nlp_doubles();
+      m = n > m ? n : m;
+    }
+  return m;
+}
+size_t persist_ws_bytes(int K, long batch, int mp) {
+  const size_t b = (size_t)batch * level_doubles(K, mp) * sizeof(double) + 64;
   return (b + 255) & ~(size_t)255;
 }
 size_t persist_region1_offset(const int *levels, long batch, int mp) { return persist_ws_bytes(levels[0] - 1, batch, mp); }
-size_t persist_level_bytes_used(int K, long batch, int mp) { return (size_t)batch * geo_of(K, 0, mp, 0, 1).nlp_doubles() * sizeof(double); }
+size_t persist_level_bytes_used(int K, long batch, int mp) { return (size_t)batch * level_doubles(K, mp) * sizeof(double); }
 size_t persist_ws_bytes_nested(const int *levels, int nlev, long batch, int mp) {
   size_t b = persist_region1_offset(levels, batch, mp);
   if (nlev > 1) b += persist_ws_bytes(levels[1] - 1, batch, mp);
@@ -1638,6 +1506,10 @@ size_t persist_ws_bytes_nested(const int *levels, int nlev, long batch, int mp) 
 
 static void launch_solve(int scheme, int form, int mp, long batch, hipStream_t stream, const ascent_params *dp, const PGeo &g, double *w,
                          int max_iter, double tol) {
+  if (scheme == 2) {      // Hermite-Simpson: ascent_hs.hip
+    hs_launch_solve(batch, stream, dp, g.K, g.Kp, g.nch, g.term, g.wide, w, max_iter, tol);
+    return;
+  }
   if (g.wide) {      // one NLP per wavefront
     const dim3 gw((unsigned)batch), bw(WAVE);
     if (mp && form == 1) hipLaunchKernelGGL((p_solve<0, 1, 1, 0, 1>), gw, bw, 0, stream, dp, batch, g, w, max_iter, tol);
@@ -1670,16 +1542,17 @@ int persist_run_nested(const ascent_params *dp, long batch, int scheme, int form
                        int max_iter, double tol, double tol_coarse, double mu0, double mu_first, double mu_next, double *dtraj,
                        double *dtf, int *dstatus, int *diters, double *dblob, hipStream_t stream, char *err, size_t errlen) {
   if (term == 2 && form != 0) { snprintf(err, errlen, "the persistent kernel carries terminal 2 for formulation 0 only"); return ASCENT_E_ARG; }
+  if (scheme == 2 && (form != 0 || mp)) { snprintf(err, errlen, "the persistent Hermite-Simpson kernel has formulation 0 without the move penalty only"); return ASCENT_E_ARG; }
   double *region[2] = {ws, (double *)((char *)ws + persist_region1_offset(levels, batch, mp))};
   const int wide = use_wide(batch, scheme, form, mp, term);
-  PGeo g = geo_of(levels[nlev - 1] - 1, form, mp, term, wide);
+  PGeo g = geo_of(levels[nlev - 1] - 1, form, mp, term, wide, scheme);
   double *w = region[(nlev - 1) & 1];
   hipLaunchKernelGGL(p_init, dim3((unsigned)((g.Kp + WAVE - 1) / WAVE), (unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g, w, dguess,
                      warm, mu0, (const double *)nullptr, (const double *)nullptr, 0);
   for (int l = nlev - 1; l >= 0; l--) {
     launch_solve(scheme, form, mp, batch, stream, dp, g, w, max_iter, l == 0 ? tol : tol_coarse);
     if (l > 0) {
-      const PGeo gf = geo_of(levels[l - 1] - 1, form, mp, term, wide);
+      const PGeo gf = geo_of(levels[l - 1] - 1, form, mp, term, wide, scheme);
       double *wf = region[(l - 1) & 1];
       hipLaunchKernelGGL(p_transfer, dim3((unsigned)((gf.Kp + WAVE - 1) / WAVE), (unsigned)batch), dim3(WAVE), 0, stream, dp, batch, g,
                          (const double *)w, gf, wf, l == nlev - 1 ? mu_first : mu_next);
@@ -1698,7 +1571,8 @@ int persist_run_nested(const ascent_params *dp, long batch, int scheme, int form
 int persist_probe(const ascent_params *dp, long batch, int scheme, int form, int mp, int term, int K, double *ws, const double *diterate, const double *dmu, const double *ddw,
                   double *dstep, int *dinertia, hipStream_t stream, char *err, size_t errlen) {
   if (term == 2 && form != 0) { snprintf(err, errlen, "the persistent kernel carries terminal 2 for formulation 0 only"); return ASCENT_E_ARG; }
-  const PGeo g = geo_of(K, form, mp, term, use_wide(batch, scheme, form, mp, term));
+  if (scheme == 2 && (form != 0 || mp)) { snprintf(err, errlen, "the persistent Hermite-Simpson kernel has formulation 0 without the move penalty only"); return ASCENT_E_ARG; }
+  const PGeo g = geo_of(K, form, mp, term, use_wide(batch, scheme, form, mp, term), scheme);
   const dim3 ng((unsigned)((g.Kp + WAVE - 1) / WAVE), (unsigned)batch);
   hipLaunchKernelGGL(p_init, ng, dim3(WAVE), 0, stream, dp, batch, g, ws, diterate, 2, 0.1, dmu, ddw, 1);
   launch_solve(scheme, form, mp, batch, stream, dp, g, ws, 1000, -1.0);

@@ -31,4 +31,9 @@ int persist_probe(const ascent_params *dp, long batch, int scheme, int form, int
 int persist_probe_rows(const ascent_params *dp, long batch, int scheme, int form, int K, double *ws, const double *diterate, const double *dzero,
                        double *ddefects, double *djac, double *dhess, hipStream_t stream, char *err, size_t errlen);
 
+// Hermite-Simpson (scheme 2) in the same layout: ascent_hs.hip.  One launch = one grid level of the batch; the node arrays are padded to
+// chunks of hs_chunk_nodes(wide) nodes (12: four NLPs per wavefront, 48: one).
+void hs_launch_solve(long batch, hipStream_t stream, const ascent_params *dp, int K, int Kp, int nch, int term, int wide, double *w, int max_iter, double tol);
+int hs_chunk_nodes(int wide);
+
 }  // namespace ascent

@@ -929,8 +929,10 @@ __global__ __launch_bounds__(WAVE) void k_terminal_params(const ascent_params *i
 }
 
 bool use_dense_path(const ascent_opts *o, int64_t batch) {
-  if (o->scheme == 2 || o->solver_path == ASCENT_PATH_DENSE) return true;
+  if (o->solver_path == ASCENT_PATH_DENSE) return true;
   const char *e = getenv("ASCENT_PIPELINE");
+  // Hermite-Simpson: the persistent kernel of ascent_hs.hip, or -- with the move penalty, or when an override names any other family -- dense blocks
+  if (o->scheme == 2 && (o->move_penalty || o->formulation != 0 || (e && strcmp(e, "persist")) || getenv("ASCENT_FACTOR"))) return true;
   // (the move penalty and terminal 2 exist in the persistent kernel and in the dense-block path: an override that names any other family means the dense one)
   if ((o->move_penalty || o->terminal == 2) && o->formulation == 0 && ((e && strcmp(e, "persist")) || getenv("ASCENT_FACTOR"))) return true;
   if (e) return !strcmp(e, "dense") && o->formulation == 0;
@@ -961,9 +963,10 @@ bool use_pcr_newton(int64_t batch, bool move_penalty = false) {
 }
 
 // The persistent kernel (ascent_persist.hip: one wavefront owns four NLPs for the whole solve, node blocks handed from the
-// node-parallel phases to the serial sweeps through LDS) -- backward Euler (both formulations) and the trapezoid.
+// node-parallel phases to the serial sweeps through LDS) -- backward Euler (both formulations), the trapezoid, and Hermite-Simpson
+// without the move penalty (ascent_hs.hip).
 bool use_persist_path(const ascent_opts *o, int64_t batch) {
-  if (o->scheme > 1 || (o->formulation != 0 && o->scheme != 0)) return false;
+  if (o->scheme > 2 || (o->formulation != 0 && o->scheme != 0) || (o->scheme == 2 && o->move_penalty)) return false;
   const char *e = getenv("ASCENT_PIPELINE");
   if (e) return !strcmp(e, "persist");
   if (getenv("ASCENT_FACTOR")) return false;          // an explicit choice between the split pipeline's sweep kernels
@@ -1335,9 +1338,9 @@ int ascent_eval_nodes_path(const ascent_params *p, int64_t batch, const ascent_o
   if (!iterate || !defects || !jac_blocks || !hess_blocks) { snprintf(g_err, sizeof g_err, "null pointer"); return ASCENT_E_ARG; }
   if (path < ASCENT_PATH_AUTO || path > ASCENT_PATH_PERSIST) { snprintf(g_err, sizeof g_err, "unknown path %d", path); return ASCENT_E_ARG; }
   path = resolve_path(path, o, batch, true);
-  if (path == ASCENT_PATH_PERSIST && (o->scheme > 1 || (o->scheme == 1 && o->formulation != 0))) { snprintf(g_err, sizeof g_err, "the persistent kernel has schemes 0 and 1 (formulation 1 with scheme 0 only)"); return ASCENT_E_ARG; }
+  if (path == ASCENT_PATH_PERSIST && (o->scheme > 2 || (o->scheme >= 1 && o->formulation != 0) || (o->scheme == 2 && o->move_penalty))) { snprintf(g_err, sizeof g_err, "the persistent kernels have schemes 0, 1 and 2 (formulation 1 with scheme 0 only; scheme 2 without the move penalty)"); return ASCENT_E_ARG; }
   if (path == ASCENT_PATH_DENSE) { snprintf(g_err, sizeof g_err, "the dense-block path exposes its node evaluation through ascent_dense_records"); return ASCENT_E_ARG; }
-  if (o->scheme == 2) { snprintf(g_err, sizeof g_err, "scheme 2 exists in the dense-block path only"); return ASCENT_E_ARG; }
+  if (o->scheme == 2) { snprintf(g_err, sizeof g_err, "the node evaluation of scheme 2 is exposed through ascent_dense_records"); return ASCENT_E_ARG; }
   if (path == ASCENT_PATH_FUSED && (o->scheme != 0 || o->formulation != 0)) { snprintf(g_err, sizeof g_err, "the fused path has scheme 0, formulation 0 only"); return ASCENT_E_ARG; }
   std::lock_guard<std::mutex> lock(g_mu[device_id]);
   HIPCHK(hipSetDevice(device_id));
@@ -1394,8 +1397,8 @@ int ascent_kkt_step_path(const ascent_params *p, int64_t batch, const ascent_opt
   if (o->move_penalty)
     for (int64_t i = 0; i < batch; i++)
       if (!(p[i].dcost > 0.0)) { snprintf(g_err, sizeof g_err, "move_penalty = 1 needs ascent_params.dcost > 0 (problem %lld has %g)", (long long)i, p[i].dcost); return ASCENT_E_ARG; }
-  if (o->scheme == 2 && path != ASCENT_PATH_DENSE) { snprintf(g_err, sizeof g_err, "scheme 2 exists in the dense-block path only"); return ASCENT_E_ARG; }
-  if (path == ASCENT_PATH_PERSIST && (o->scheme > 1 || (o->scheme == 1 && o->formulation != 0))) { snprintf(g_err, sizeof g_err, "the persistent kernel has schemes 0 and 1 (formulation 1 with scheme 0 only)"); return ASCENT_E_ARG; }
+  if (o->scheme == 2 && path != ASCENT_PATH_DENSE && path != ASCENT_PATH_PERSIST) { snprintf(g_err, sizeof g_err, "scheme 2 exists in the persistent Hermite-Simpson kernel and in the dense-block path only"); return ASCENT_E_ARG; }
+  if (path == ASCENT_PATH_PERSIST && (o->scheme > 2 || (o->scheme >= 1 && o->formulation != 0) || (o->scheme == 2 && o->move_penalty))) { snprintf(g_err, sizeof g_err, "the persistent kernels have schemes 0, 1 and 2 (formulation 1 with scheme 0 only; scheme 2 without the move penalty)"); return ASCENT_E_ARG; }
   if (path == ASCENT_PATH_DENSE && o->formulation != 0) { snprintf(g_err, sizeof g_err, "the dense-block path has formulation 0 only"); return ASCENT_E_ARG; }
   if (path == ASCENT_PATH_FUSED && (o->scheme != 0 || o->formulation != 0)) { snprintf(g_err, sizeof g_err, "the fused path has scheme 0, formulation 0 only"); return ASCENT_E_ARG; }
   std::lock_guard<std::mutex> lock(g_mu[device_id]);

@@ -108,8 +108,9 @@ def test_product_does_not_import_oracle():
 def test_default_path_dispatch_rule(monkeypatch):
     """ascent_default_path (include/ascent.h): which kernels a solve of that size runs -- no device work, so checked here.
     Schemes 0 and 1 and the v1 formulation: the persistent kernel, except (formulation 0) a handful of NLPs on a long grid
-    (>= 400 intervals, batch <= min(6, intervals/300)), which take the dense blocks + PCR; scheme 2: dense blocks always.  The
-    move penalty (ascent_opts.move_penalty, the reference's DCOST) rides in the persistent kernel for schemes 0 and 1."""
+    (>= 400 intervals, batch <= min(6, intervals/300)), which take the dense blocks + PCR; scheme 2 (Hermite-Simpson): its own
+    persistent kernel by the same rule, dense blocks with the move penalty.  The move penalty (ascent_opts.move_penalty, the
+    reference's DCOST) rides in the persistent kernel for schemes 0 and 1."""
     import lunar_module_ascent_trajectory_optimiser_amd as A
     for k in ("ASCENT_PIPELINE", "ASCENT_FACTOR", "ASCENT_SMALL_BATCH", "ASCENT_DENSE_NEWTON"):
         monkeypatch.delenv(k, raising=False)
@@ -119,7 +120,8 @@ def test_default_path_dispatch_rule(monkeypatch):
     assert [A.default_path(b, 201, scheme=1) for b in (1, 8, 4096, 65536)] == ["persist"] * 4
     assert [A.default_path(b, 2000, scheme=1) for b in (6, 7)] == ["dense", "persist"]
     assert [A.default_path(b, 201, formulation=1) for b in (1, 4096, 8192)] == ["persist"] * 3 and A.default_path(4, 2000, formulation=1) == "persist"
-    assert A.default_path(4096, 201, scheme=2) == "dense"
+    assert [A.default_path(b, 201, scheme=2) for b in (1, 256, 4096, 65536)] == ["persist"] * 4
+    assert [A.default_path(b, 2000, scheme=2) for b in (1, 6, 7, 256)] == ["dense", "dense", "persist", "persist"]
     assert [A.default_path(b, 201, scheme=sc, move_penalty=True) for b in (1, 4096) for sc in (0, 1, 2)] == ["persist", "persist", "dense"] * 2     # the l1 move penalty
     assert A.default_path(4096, 201, move_penalty=True) == "persist" and A.default_path(2, 2000, move_penalty=True) == "dense"
     assert A.default_path(1, 2000) == "dense"
@@ -128,6 +130,7 @@ def test_default_path_dispatch_rule(monkeypatch):
     monkeypatch.setenv("ASCENT_PIPELINE", "split")
     assert A.default_path(4096, 201) == "split_wide"
     assert A.default_path(4096, 201, move_penalty=True) == "dense"        # (the split pipeline does not carry the penalty)
+    assert A.default_path(4096, 201, scheme=2) == "dense"                  # (... nor Hermite-Simpson)
 
 
 def test_persistent_workspace_regions_fit_the_allocation(lib):
