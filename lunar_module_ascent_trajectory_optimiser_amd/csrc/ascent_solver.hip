@@ -945,6 +945,9 @@ bool use_dense_path(const ascent_opts *o, int64_t batch) {
   const char *sb = getenv("ASCENT_SMALL_BATCH");
   if (sb && !strcmp(sb, "off")) return false;
   if (o->formulation != 0 || getenv("ASCENT_FACTOR")) return false;
+  // (terminal 2 has no cyclic-reduction variant -- see the note at `pcr` in ascent_solve_batch --, and the dense Riccati recursion of one
+  //  wavefront loses to the persistent kernels at every size: one NLP at N=2000 Hermite-Simpson 131 ms against 50)
+  if (o->terminal == 2) return false;
   const int64_t K = (int64_t)o->n_nodes - 1;
   const int64_t lim = K < 400 ? 0 : (K / 300 < 6 ? K / 300 : 6);
   return batch <= lim;

@@ -114,11 +114,10 @@ def solve_batch(params, nt: int = 200, tol: float = 1e-9, max_iter: int = 300, g
     """Solve a batch of ascent NLPs on one GPU.  params: AscentParams | list | (batch,16) array.
     guess: (21K+10, batch) blob, with warm_start 1 (primal only) or 2 (primal-dual).
     scheme: 0 / "backward_euler" (the reference's NODES=2), 1 / "trapezoid" or 2 / "hermite_simpson" (both with the
-    control held over the step; scheme 2 runs on the dense-block solver path).
+    control held over the step; scheme 2 runs in a persistent kernel of its own, with the move penalty on the dense-block path).
     terminal: 0 / "reference" (Launch_Optimiser.py:72-78), 1 / "ellipse" (the (r_peri, r_apo) ellipse proper: vis-viva
     speed at its periapsis; `BatchResult.coast()` then ends at its apoapsis) or 2 / "ellipse_free" (burnout anywhere on that
-    ellipse: its angular momentum and energy, no r.v = 0; the coast starts at whatever true anomaly the burn ends at;
-    dense-block path).
+    ellipse: its angular momentum and energy, no r.v = 0; the coast starts at whatever true anomaly the burn ends at).
     path: "auto" or "dense" (the dense-block path for any scheme).
     move_penalty: apply the reference's MV DCOST (Launch_Optimiser.py:99): objective tf + dcost * sum |u_k - u_{k-1}| with the
     `dcost` of each parameter set (schemes 0 / 1: inside the persistent kernel, the control as the eighth state of a stage;
@@ -292,9 +291,9 @@ def solve_batch_torch(params_t, nt: int = 200, tol: float = 1e-9, max_iter: int 
     return out
 
 
-def default_path(batch: int, nt: int = 200, scheme=0, formulation=0, move_penalty: bool = False) -> str:
+def default_path(batch: int, nt: int = 200, scheme=0, formulation=0, move_penalty: bool = False, terminal=0) -> str:
     """The kernels solve_batch runs for a batch of this size (include/ascent.h: ascent_default_path): a key of _lib.PATHS."""
-    o = _opts(nt, 300, 1e-9, 0, 0.0, scheme, formulation, move_penalty=move_penalty)
+    o = _opts(nt, 300, 1e-9, 0, 0.0, scheme, formulation, move_penalty=move_penalty, terminal=terminal)
     code = _lib.load().ascent_default_path(int(batch), C.byref(o))
     return {v: k for k, v in _lib.PATHS.items()}[code]
 

@@ -294,8 +294,8 @@ def test_pcr_newton_variant_and_small_batch_dispatch(coracle, monkeypatch):
     """The dense-block path solves its Newton systems by the serial Riccati recursion (one wavefront per NLP) or by
     parallel cyclic reduction over the collocation nodes (one wavefront per node, 15x15 blocks on MFMA FP64 tiles;
     ASCENT_DENSE_NEWTON=riccati|pcr, automatic: PCR up to 64 NLPs).  Same Newton step to rounding; same iterates, so the
-    same iteration counts and answers -- also the oracle's.  Batches of up to 8 NLPs of schemes 0/1 are routed to the
-    dense-block path with PCR automatically (ASCENT_SMALL_BATCH=off keeps the hand-tuned kernels): all three agree."""
+    same iteration counts and answers -- also the oracle's.  A handful of NLPs on a long grid are routed to the dense-block path
+    with PCR automatically (ASCENT_SMALL_BATCH=off keeps the persistent kernels, scheme 2's included): all agree."""
     nt = 40
     S = A.sweep_isp_drymass(2, 2)
     blobs = _interior_blobs(coracle, S, nt, 2)
@@ -306,7 +306,7 @@ def test_pcr_newton_variant_and_small_batch_dispatch(coracle, monkeypatch):
         steps[mode] = A.kkt_step(S, blobs, mu, dw, nt, path="dense", scheme=2)
     assert np.array_equal(steps["riccati"][1], steps["pcr"][1]) and not steps["pcr"][1].any()
     assert np.abs(steps["riccati"][0] - steps["pcr"][0]).max() <= 1e-9 * np.abs(steps["riccati"][0]).max()
-    for B, ntf, scheme in ((1, 200, 0), (5, 200, 1), (3, 200, 2), (1, 1000, 0), (9, 60, 0)):
+    for B, ntf, scheme in ((1, 200, 0), (5, 200, 1), (3, 200, 2), (1, 1000, 0), (2, 1000, 2), (9, 60, 0)):
         P = np.vstack([A.AscentParams().as_row()[None], A.sweep_isp_drymass(3, 3)])[:B]
         res = {}
         for name, env in (("pcr", {"ASCENT_DENSE_NEWTON": "pcr"}), ("riccati", {"ASCENT_DENSE_NEWTON": "riccati"}),
@@ -314,11 +314,9 @@ def test_pcr_newton_variant_and_small_batch_dispatch(coracle, monkeypatch):
             monkeypatch.delenv("ASCENT_DENSE_NEWTON", raising=False); monkeypatch.delenv("ASCENT_SMALL_BATCH", raising=False)
             for k_, v_ in env.items():
                 monkeypatch.setenv(k_, v_)
-            if name == "hand" and scheme == 2:
-                continue
             res[name] = A.solve_batch(P, ntf, tol=1e-9, scheme=scheme, max_iter=500, path="dense" if name in ("pcr", "riccati") else "auto")
             assert np.all(res[name].status == 0)
-        auto_is_pcr = scheme == 2 or B <= (0 if ntf - 1 < 400 else min(6, (ntf - 1) // 300))     # the dispatch rule (ascent_solver.hip)
+        auto_is_pcr = B <= (0 if ntf - 1 < 400 else min(6, (ntf - 1) // 300))     # the dispatch rule (ascent_solver.hip)
         monkeypatch.delenv("ASCENT_SMALL_BATCH", raising=False)
         assert A.default_path(B, ntf, scheme=scheme) == ("dense" if auto_is_pcr else "persist")
         for name in res:
