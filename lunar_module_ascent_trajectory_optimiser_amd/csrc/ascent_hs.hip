@@ -199,9 +199,14 @@ ASC_DEV void hs_rows(const HsJ &J, double X[4][7], double Ab[4][7]) {
 // The trial point x + alpha dx at the nodes of a chunk (iterate ic, step stp), stored into the other iterate buffer, and its pieces of the
 // l1 merit function and of the KKT error.  The stationarity row of node k holds Jb_k'lambda_k + Ja_{k+1}'lambda_{k+1}: the second term
 // comes from the lane of step k+1, or -- at the end of a chunk -- from the carry the chunk above has left (chunks run downwards).
-template <int TERM, int WIDE>
-ASC_DEV void hs_trial_chunk(const Der &d, int K, int Kp, int k, bool on, int nl, int CHN, const double *ic, const double *stp, double *in,
-                            const TrialCtx &t, bool live, double *carry, Part &P) {
+// (A function of its own -- one register allocation per node-parallel evaluation, see hs_eval_factor below; the scalars of the trial point
+//  come from the NLP's record in LDS: iterate X_S, step X_D.)
+struct HsTrial { double alpha, adu, mu, dt, hT; bool first; };
+template <int TERM>
+ASC_PASS Part hs_trial_chunk(const Der *dp, const double *sc, int K, int Kp, int k, bool on, bool lastl, bool firstl, const double *ic, const double *stp,
+                             double *in, HsTrial t, bool live, double *carry, Part P) {
+  const Der d = *dp;
+  const double be = t.dt * d.alpha, mlo = t.mu * 1e-10, mhi = t.mu * 1e10;
   double ga[7] = {0, 0, 0, 0, 0, 0, 0}, r[7] = {0, 0, 0, 0, 0, 0, 0};
   if (on) {
     const double alpha = t.alpha;
@@ -229,7 +234,7 @@ ASC_DEV void hs_trial_chunk(const Der &d, int K, int Kp, int k, bool on, int nl,
     ASC_UNROLL
     for (int b = 0; b < 6; b++) {
       const double id = rcp(dist[b]);
-      zb[b] = t.first ? zb[b] : fmin(fmax(zb[b] + t.adu * dzb[b], t.mlo * id), t.mhi * id);
+      zb[b] = t.first ? zb[b] : fmin(fmax(zb[b] + t.adu * dzb[b], mlo * id), mhi * id);
     }
     if (live) {
       ASC_UNROLL
@@ -256,7 +261,7 @@ ASC_DEV void hs_trial_chunk(const Der &d, int K, int Kp, int k, bool on, int nl,
     r[IA] += zb[1] - zb[0];
     r[IM] += zb[3] - zb[2];
     if (k == K - 1) {
-      const Scal &stt = t.stt;
+      const Scal stt = trial_scal(d, lds_scal(sc, X_S), lds_scal(sc, X_D), t.alpha, t.adu, t.mu, t.first);
       const Terminal tt = TERM == 2 ? terminal_eval_any(d, z) : terminal_eval(d, z);
       const double e1 = fabs(tt.e3), e2 = fabs(tt.g1 - stt.s1), e3 = fabs(tt.g2 - stt.s2);
       P.cinf = fmax(P.cinf, fmax(e1, fmax(e2, e3)));
@@ -278,7 +283,7 @@ ASC_DEV void hs_trial_chunk(const Der &d, int K, int Kp, int k, bool on, int nl,
     for (int b = 0; b < 6; b++) { const double pr = dist[b] * zb[b]; P.pmin = fmin(P.pmin, pr); P.pmax = fmax(P.pmax, pr); P.zsum += zb[b]; }
     const double pa = dist[0] * dist[1], pm = dist[2] * dist[3], pu = dist[4] * dist[5];
     P.sl += (pa > 0.0 && pm > 0.0 && pu > 0.0) ? log(pa * pm * pu) : NAN;
-    const double ruv = -t.be * l[IW] - zb[4] + zb[5];
+    const double ruv = -be * l[IW] - zb[4] + zb[5];
     P.rd = fmax(P.rd, fabs(ruv));
   }
   double gn[7];
@@ -287,16 +292,348 @@ ASC_DEV void hs_trial_chunk(const Der &d, int K, int Kp, int k, bool on, int nl,
   if (on) {
     ASC_UNROLL
     for (int i = 0; i < 7; i++) {
-      const double g1 = k == K - 1 ? 0.0 : nl == CHN - 1 ? carry[C_TG + i] : gn[i];
+      const double g1 = k == K - 1 ? 0.0 : lastl ? carry[C_TG + i] : gn[i];
       P.rd = fmax(P.rd, fabs(r[i] + g1));
     }
   }
   wsync();
-  if (on && nl == 0) {
+  if (on && firstl) {
     ASC_UNROLL
     for (int i = 0; i < 7; i++) carry[C_TG + i] = ga[i];
   }
   wsync();
+  return P;
+}
+
+// ---- node-parallel evaluations as functions ---------------------------------------------------------------------------------------
+// Each evaluation below keeps 150-200 doubles alive (three evaluation points with first derivatives, the midpoint's Hessian, four
+// products with F', both Jacobians' coefficients); inlined into h_solve next to the state the serial sweeps carry across a chunk they
+// exceed the 512 registers of a wavefront, and the spills came back one load and one wait at a time (30 dependent scratch round trips per
+// evaluation: more stall than arithmetic).  As functions they have a register allocation of their own and the caller's state is saved
+// around the call in one burst.  Lane = node k (step k: nodes k-1, k); lastl / firstl: the last / first node of the chunk.
+
+// Factorisation phase: the step's blocks into the LDS stage (column col).  Returns the step's part of the (theta, theta) entry.
+ASC_PASS double hs_eval_factor(const Der *dp, const double *it, double *stage, double *carry, int K, int Kp, int k, bool on, bool lastl, bool firstl,
+                               int col, double h, double hT, double mu, double dw) {
+  const Der d = *dp;
+  const double bu = h * d.alpha;
+  HsPts pt;
+  HsDual q;
+  double Hath[7] = {0, 0, 0, 0, 0, 0, 0}, Hbth[7], zb6[6], z[7], u = 0.0, lw = 0.0, Hthth = 0.0;
+  ASC_UNROLL
+  for (int i = 0; i < 7; i++) { q.ga[i] = 0.0; }
+  q.wa[0] = 0.0; q.wa[1] = 0.0;
+  if (on) {
+    double zp[7], l[7];
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) {
+      z[i] = it[(O_Z + i) * Kp + k]; zp[i] = k > 0 ? it[(O_Z + i) * Kp + k - 1] : 0.0; l[i] = it[(O_L + i) * Kp + k];
+    }
+    u = it[O_U * Kp + k]; lw = l[IW];
+    ASC_UNROLL
+    for (int b = 0; b < 6; b++) zb6[b] = it[(O_ZB + b) * Kp + k];
+    hs_points<1>(d, zp, z, u, h, l[IVX], l[IVY], pt);
+    hs_dual(pt, l, h, q);
+    double cc[7], Jth[7];
+    hs_defect(pt, zp, z, h, hT, cc, Jth);
+    hs_theta(pt, q, h, hT, Hath, Hbth, Hthth);
+    double eb[4], es[4];
+    hs_blocks(pt.Gb, pt.Gm, h, eb, es);
+    const double sm = (4.0 / 6.0) * h;
+    ASC_UNROLL
+    for (int i = 0; i < 8; i++) {
+      stage[(H_GA + i) * LDH + col] = pt.Ga[i]; stage[(H_GM + i) * LDH + col] = pt.Gm[i]; stage[(H_GB + i) * LDH + col] = pt.Gb[i];
+    }
+    ASC_UNROLL
+    for (int i = 0; i < 4; i++) { stage[(H_EB + i) * LDH + col] = eb[i]; stage[(H_ES + i) * LDH + col] = es[i]; }
+    ASC_UNROLL
+    for (int i = 0; i < 10; i++) stage[(H_W + i) * LDH + col] = -sm * pt.Hm[i];
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) { stage[(H_C + i) * LDH + col] = cc[i]; stage[(H_JT + i) * LDH + col] = Jth[i]; }
+  }
+  // from the lane of step k+1 (or the carry of the chunk above): Ja'lambda, the theta column's entries on node k, the end-point weights
+  double gan[7], han[7], wan[2];
+  ASC_UNROLL
+  for (int i = 0; i < 7; i++) { gan[i] = __shfl_down(q.ga[i], 1); han[i] = __shfl_down(Hath[i], 1); }
+  wan[0] = __shfl_down(q.wa[0], 1); wan[1] = __shfl_down(q.wa[1], 1);
+  if (on) {
+    if (k == K - 1) {
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) { gan[i] = 0.0; han[i] = 0.0; }
+      wan[0] = 0.0; wan[1] = 0.0;
+    } else if (lastl) {
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) { gan[i] = carry[C_GA + i]; han[i] = carry[C_HA + i]; }
+      wan[0] = carry[C_WA]; wan[1] = carry[C_WA + 1];
+    }
+    double Hn[10], Gx[8], t1, t2;
+    accel<2>(d, z[IX], z[IY], z[IA], z[IM], q.wb[0] + wan[0], q.wb[1] + wan[1], t1, t2, Gx, Hn);
+    const double dist[6] = {z[IA], d.aub - z[IA], z[IM], 1.0 - z[IM], u + 1.0, 1.0 - u};
+    double id[6];
+    ASC_UNROLL
+    for (int b = 0; b < 6; b++) id[b] = rcp(dist[b]);
+    ASC_UNROLL
+    for (int i = 0; i < 10; i++) Hn[i] = -Hn[i];
+    Hn[7] += zb6[0] * id[0] + zb6[1] * id[1];
+    Hn[9] += zb6[2] * id[2] + zb6[3] * id[3];
+    ASC_UNROLL
+    for (int i = 0; i < 10; i++) stage[(H_H + i) * LDH + col] = Hn[i];
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) {
+      double rz = q.gb[i] + gan[i];
+      if (i == IA) rz += mu * (id[1] - id[0]);
+      if (i == IM) rz += mu * (id[3] - id[2]);
+      stage[(H_RZ + i) * LDH + col] = rz;
+      stage[(H_GT + i) * LDH + col] = Hbth[i] + han[i];
+    }
+    stage[H_R0 * LDH + col] = zb6[4] * id[4] + zb6[5] * id[5] + dw;
+    stage[(H_R0 + 1) * LDH + col] = -bu * lw + mu * (id[5] - id[4]);
+    stage[(H_R0 + 2) * LDH + col] = -hT * d.alpha * lw;
+  }
+  wsync();
+  if (on && firstl) {
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) { carry[C_GA + i] = q.ga[i]; carry[C_HA + i] = Hath[i]; }
+    carry[C_WA] = q.wa[0]; carry[C_WA + 1] = q.wa[1];
+  }
+  wsync();
+  return Hthth;
+}
+
+// Forward phase: the node-local coefficients of dz_k = M_k dz_{k-1} + v_k (rows 7 i .. 7 i + 5: M[i][0..5], row 7 i + 6: v[i]; lane 6: du) into the
+// stage, the mass component by a prefix sum over the nodes (row F_OUT + 6).  carry_m: dz_m of the last node of the chunk before; returns the new one.
+constexpr int F_OUT = 49, A_RHS = 42, A_C = 49, A_J = 56;      // (adjoint: rhs, defect and the coefficients of Jb stashed beside the recursion's rows)
+template <int WIDE>
+ASC_PASS double hs_eval_forward(const Der *dp, const double *it, const double *gains, double *stage, int K, int Kp, int kn, bool on, int nl, int col,
+                                double h, double hT, double dth, double dnu3, double carry_m) {
+  const Der d = *dp;
+  const double bu = h * d.alpha;
+  double x0m = 0.0, du00 = 0.0, ka[7], rc[7];
+  HsJ J;
+  if (on) {
+    double z[7], zp[7];
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) { z[i] = it[(O_Z + i) * Kp + kn]; zp[i] = kn > 0 ? it[(O_Z + i) * Kp + kn - 1] : 0.0; }
+    const double u_ = it[O_U * Kp + kn];
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) ka[i] = gains[(size_t)i * Kp + kn];
+    du00 = -(gains[(size_t)7 * Kp + kn] + gains[(size_t)8 * Kp + kn] * dth + gains[(size_t)9 * Kp + kn] * dnu3);
+    HsPts pt;
+    hs_points<0>(d, zp, z, u_, h, 0.0, 0.0, pt);
+    double cc[7], Jth[7], eb[4], es[4];
+    hs_defect(pt, zp, z, h, hT, cc, Jth);
+    hs_blocks(pt.Gb, pt.Gm, h, eb, es);
+    hs_coeffs(pt.Ga, pt.Gm, pt.Gb, eb, es, h, bu, J);
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) rc[i] = cc[i] + Jth[i] * dth;
+    x0m = -rc[IM];
+  }
+  // dz_m: inclusive prefix sum of x0_m over the nodes of the NLP (the chunk here, the chunks before in carry_m)
+  double incl = x0m;
+  ASC_UNROLL
+  for (int sft = 1; sft < (WIDE ? 64 : 16); sft *= 2) {
+    const double t = __shfl_up(incl, sft, WIDE ? 64 : 16);
+    if (nl >= sft) incl += t;
+  }
+  const double dzm_k = carry_m + incl, dzm_p = dzm_k - x0m;
+  carry_m += WIDE ? __shfl(incl, HCW - 1) : bcast16<HCH - 1>(incl);
+  if (on) {
+    constexpr int NC = 6, FS = 7;
+    const double du00p = du00 - ka[IM] * dzm_p;
+    double X[4][7], Ab[4][7];
+    hs_rows(J, X, Ab);
+    auto emit = [&](int i, const double *xr_, const double *ar) {       // row i: its row of Jb^-1 and of Abar
+      const double bw = bu * xr_[IW];
+      double v = bw * du00p + ar[IM] * dzm_p;
+      ASC_UNROLL
+      for (int j = 0; j < 7; j++) v -= xr_[j] * rc[j];
+      ASC_UNROLL
+      for (int j = 0; j < 6; j++) stage[(FS * i + j) * LDH + col] = ar[j] - bw * ka[j];
+      stage[(FS * i + NC) * LDH + col] = v;
+    };
+    emit(IX, X[0], Ab[0]); emit(IY, X[1], Ab[1]); emit(IVX, X[2], Ab[2]); emit(IVY, X[3], Ab[3]);
+    {
+      const double xa[7] = {0, 0, 0, 0, 1.0, 0.5 * h, 0}, aa[7] = {0, 0, 0, 0, 1.0, h, 0};
+      emit(IA, xa, aa);
+      const double xw[7] = {0, 0, 0, 0, 0, 1.0, 0}, aw[7] = {0, 0, 0, 0, 0, 1.0, 0};
+      emit(IW, xw, aw);
+    }
+    ASC_UNROLL
+    for (int j = 0; j < 6; j++) stage[(42 + j) * LDH + col] = -ka[j];
+    stage[48 * LDH + col] = du00p;
+    stage[(F_OUT + 6) * LDH + col] = dzm_k;
+  }
+  wsync();
+  return carry_m;
+}
+
+// Adjoint phase: rhs_k (everything of node k's stationarity row that the forward sweep has fixed), the coefficients of
+// psi_{k-1} = Abar_k' (psi_k - rhs_k) into rows 6 i .. 6 i + 5 of the stage, and -- for the part after the sweep -- rhs, the defect and the
+// coefficients of Jb into rows A_RHS / A_C / A_J of the lane's column.  Returns c . lambda of the node.
+template <int TERM>
+ASC_PASS double hs_eval_adjoint(const Der *dp, const double *sc, const double *it, const double *stp, double *stage, double *carry, int K, int Kp, int kn,
+                                bool on, bool lastl, bool firstl, int col, double h, double hT, double mu, double dw, double dth, double dnu3) {
+  const Der d = *dp;
+  const double bu = h * d.alpha, e8 = 0.125 * h;
+  double ccl = 0.0, ccn[7], rhs[7] = {0, 0, 0, 0, 0, 0, 0};
+  double om[4] = {0, 0, 0, 0}, Hath[7] = {0, 0, 0, 0, 0, 0, 0}, Hbth[7];
+  HsJ J;
+  HsPts pt;
+  HsDual q;
+  ASC_UNROLL
+  for (int i = 0; i < 7; i++) q.ga[i] = 0.0;
+  q.wa[0] = 0.0; q.wa[1] = 0.0;
+  double z[7], dz[7], zb6[4];
+  if (on) {
+    double zp[7], l[7], dzp[7];
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) {
+      z[i] = it[(O_Z + i) * Kp + kn]; zp[i] = kn > 0 ? it[(O_Z + i) * Kp + kn - 1] : 0.0; l[i] = it[(O_L + i) * Kp + kn];
+      dz[i] = stp[(O_Z + i) * Kp + kn]; dzp[i] = kn > 0 ? stp[(O_Z + i) * Kp + kn - 1] : 0.0;
+    }
+    const double u = it[O_U * Kp + kn];
+    ASC_UNROLL
+    for (int b = 0; b < 4; b++) zb6[b] = it[(O_ZB + b) * Kp + kn];
+    hs_points<1>(d, zp, z, u, h, l[IVX], l[IVY], pt);
+    hs_dual(pt, l, h, q);
+    double Jth[7], Hthth, eb[4], es[4];
+    hs_defect(pt, zp, z, h, hT, ccn, Jth);
+    hs_theta(pt, q, h, hT, Hath, Hbth, Hthth);
+    hs_blocks(pt.Gb, pt.Gm, h, eb, es);
+    hs_coeffs(pt.Ga, pt.Gm, pt.Gb, eb, es, h, bu, J);
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) ccl += ccn[i] * l[i];
+    // omega = W (La dz_{k-1} + Lb dz_k) on (x, y, angle, mass)
+    const double xi[4] = {0.5 * (dzp[IX] + dz[IX]) + e8 * (dzp[IVX] - dz[IVX]), 0.5 * (dzp[IY] + dz[IY]) + e8 * (dzp[IVY] - dz[IVY]),
+                          0.5 * (dzp[IA] + dz[IA]) + e8 * (dzp[IW] - dz[IW]), 0.5 * (dzp[IM] + dz[IM])};
+    const double sm = (4.0 / 6.0) * h;
+    const double *H = pt.Hm;
+    om[0] = -sm * (H[0] * xi[0] + H[1] * xi[1] + H[2] * xi[2] + H[3] * xi[3]);
+    om[1] = -sm * (H[1] * xi[0] + H[4] * xi[1] + H[5] * xi[2] + H[6] * xi[3]);
+    om[2] = -sm * (H[2] * xi[0] + H[5] * xi[1] + H[7] * xi[2] + H[8] * xi[3]);
+    om[3] = -sm * (H[3] * xi[0] + H[6] * xi[1] + H[8] * xi[2] + H[9] * xi[3]);
+  }
+  double gan[7], han[7], wan[2], omn[4];
+  ASC_UNROLL
+  for (int i = 0; i < 7; i++) { gan[i] = __shfl_down(q.ga[i], 1); han[i] = __shfl_down(Hath[i], 1); }
+  wan[0] = __shfl_down(q.wa[0], 1); wan[1] = __shfl_down(q.wa[1], 1);
+  ASC_UNROLL
+  for (int r = 0; r < 4; r++) omn[r] = __shfl_down(om[r], 1);
+  if (on) {
+    if (kn == K - 1) {
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) { gan[i] = 0.0; han[i] = 0.0; }
+      wan[0] = 0.0; wan[1] = 0.0;
+      ASC_UNROLL
+      for (int r = 0; r < 4; r++) omn[r] = 0.0;
+    } else if (lastl) {
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) { gan[i] = carry[C_GA + i]; han[i] = carry[C_HA + i]; }
+      wan[0] = carry[C_WA]; wan[1] = carry[C_WA + 1];
+      ASC_UNROLL
+      for (int r = 0; r < 4; r++) omn[r] = carry[C_OM + r];
+    }
+    double Hn[10], Gx[8], t1, t2;
+    accel<2>(d, z[IX], z[IY], z[IA], z[IM], q.wb[0] + wan[0], q.wb[1] + wan[1], t1, t2, Gx, Hn);
+    const double id0 = rcp(z[IA]), id1 = rcp(d.aub - z[IA]), id2 = rcp(z[IM]), id3 = rcp(1.0 - z[IM]);
+    ASC_UNROLL
+    for (int i = 0; i < 10; i++) Hn[i] = -Hn[i];
+    Hn[7] += zb6[0] * id0 + zb6[1] * id1;
+    Hn[9] += zb6[2] * id2 + zb6[3] * id3;
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) rhs[i] = (q.gb[i] + gan[i]) + (Hbth[i] + han[i]) * dth + dw * dz[i];
+    rhs[IA] += mu * (id1 - id0);
+    rhs[IM] += mu * (id3 - id2);
+    rhs[IX] += Hn[0] * dz[IX] + Hn[1] * dz[IY] + Hn[2] * dz[IA] + Hn[3] * dz[IM];
+    rhs[IY] += Hn[1] * dz[IX] + Hn[4] * dz[IY] + Hn[5] * dz[IA] + Hn[6] * dz[IM];
+    rhs[IA] += Hn[2] * dz[IX] + Hn[5] * dz[IY] + Hn[7] * dz[IA] + Hn[8] * dz[IM];
+    rhs[IM] += Hn[3] * dz[IX] + Hn[6] * dz[IY] + Hn[8] * dz[IA] + Hn[9] * dz[IM];
+    // the midpoint terms: Lb_k' omega_k + La_{k+1}' omega_{k+1}
+    rhs[IX] += 0.5 * (om[0] + omn[0]); rhs[IY] += 0.5 * (om[1] + omn[1]); rhs[IA] += 0.5 * (om[2] + omn[2]); rhs[IM] += 0.5 * (om[3] + omn[3]);
+    rhs[IVX] += e8 * (omn[0] - om[0]); rhs[IVY] += e8 * (omn[1] - om[1]); rhs[IW] += e8 * (omn[2] - om[2]);
+    if (kn == K - 1) {
+      const Scal s = lds_scal(sc, X_S);
+      const double sig1 = sc[X_SIG1], sig2 = sc[X_SIG2], rs1 = sc[X_RS1], rs2 = sc[X_RS2];
+      double QT[28], qd[7];
+      const Terminal tm = TERM == 2 ? terminal_eval_any(d, z) : terminal_eval(d, z);
+      ASC_UNROLL
+      for (int i = 0; i < 28; i++) QT[i] = 0.0;
+      if constexpr (TERM == 2) terminal_hessian_any(QT, tm, s.nu1, s.nu2, sig1, sig2);
+      else terminal_hessian(QT, tm, s.nu3, s.nu1, s.nu2, sig1, sig2);
+      symv(QT, dz, qd);
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) rhs[i] += qd[i];
+      const double w1 = s.nu1 + sig1 * sc[X_CG1] + rs1, w2 = s.nu2 + sig2 * sc[X_CG2] + rs2;
+      if constexpr (TERM == 2) {
+        double g4[4];
+        terminal_grad_any(tm, w1, w2, g4);
+        rhs[IX] += g4[0]; rhs[IY] += g4[1]; rhs[IVX] += g4[2]; rhs[IVY] += g4[3];
+      } else {
+        rhs[IX] += s.nu3 * tm.e3g[0] + w1 * tm.g1g[0] + tm.e3g[0] * dnu3;
+        rhs[IY] += s.nu3 * tm.e3g[1] + w1 * tm.g1g[1] + tm.e3g[1] * dnu3;
+        rhs[IVX] += s.nu3 * tm.e3g[2] + w2 * tm.g2g[0] + tm.e3g[2] * dnu3;
+        rhs[IVY] += s.nu3 * tm.e3g[3] + w2 * tm.g2g[1] + tm.e3g[3] * dnu3;
+      }
+    }
+    // coefficients: column j = x, y, xdot, ydot of Abar' is row j of Abar; column angle is e_a + h e_w; w = -Abar' rhs = Ja' Jb^-T rhs
+    double X[4][7], Ab[4][7];
+    hs_rows(J, X, Ab);
+    double xs[7], o8[8];
+    hs_solve_jbt(J, rhs, xs);
+    hs_apply_j8t(J, xs, o8);
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) {
+      ASC_UNROLL
+      for (int j = 0; j < 4; j++) stage[(6 * i + j) * LDH + col] = Ab[j][i];
+      stage[(6 * i + 4) * LDH + col] = i == IA ? 1.0 : i == IW ? h : 0.0;
+      stage[(6 * i + 5) * LDH + col] = -o8[i];
+      stage[(A_RHS + i) * LDH + col] = rhs[i];
+      stage[(A_C + i) * LDH + col] = ccn[i];
+    }
+    const double jc[22] = {J.eb[0], J.eb[1], J.eb[2], J.eb[3], J.es[0], J.es[1], J.es[2], J.es[3], J.b21[0], J.b21[1], J.b21[2], J.b21[3],
+                           J.caq[0], J.caq[1], J.cav[0], J.cav[1], J.cwv[0], J.cwv[1], J.cmq[0], J.cmq[1], J.cmv[0], J.cmv[1]};
+    ASC_UNROLL
+    for (int i = 0; i < 22; i++) stage[(A_J + i) * LDH + col] = jc[i];
+  }
+  wsync();
+  if (on && firstl) {
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) { carry[C_GA + i] = q.ga[i]; carry[C_HA + i] = Hath[i]; }
+    carry[C_WA] = q.wa[0]; carry[C_WA + 1] = q.wa[1];
+    ASC_UNROLL
+    for (int r = 0; r < 4; r++) carry[C_OM + r] = om[r];
+  }
+  return ccl;
+}
+// ... and after the sweep: Jb_k' dlam_k = psi_k - rhs_k (psi: rows 0-6 of the next column, or the carry at the end of a chunk); returns c . dlambda
+ASC_PASS double hs_post_adjoint(double *stage, const double *carry, double *stp, int K, int Kp, int kn, bool on, bool lastl, int col, double h, bool live) {
+  double ccl = 0.0;
+  if (on) {
+    HsJ J;
+    double jc[22];
+    ASC_UNROLL
+    for (int i = 0; i < 22; i++) jc[i] = stage[(A_J + i) * LDH + col];
+    ASC_UNROLL
+    for (int i = 0; i < 4; i++) { J.eb[i] = jc[i]; J.es[i] = jc[4 + i]; J.b21[i] = jc[8 + i]; }
+    ASC_UNROLL
+    for (int i = 0; i < 2; i++) { J.caq[i] = jc[12 + i]; J.cav[i] = jc[14 + i]; J.cwv[i] = jc[16 + i]; J.cmq[i] = jc[18 + i]; J.cmv[i] = jc[20 + i]; }
+    J.hh = 0.5 * h;
+    double ph[7], dl[7];
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) {
+      const double psi = kn + 1 < K ? (lastl ? carry[C_PSI + i] : stage[i * LDH + col + 1]) : 0.0;
+      ph[i] = psi - stage[(A_RHS + i) * LDH + col];
+    }
+    hs_solve_jbt(J, ph, dl);
+    ASC_UNROLL
+    for (int i = 0; i < 7; i++) ccl += stage[(A_C + i) * LDH + col] * dl[i];
+    if (live) {
+      ASC_UNROLL
+      for (int i = 0; i < 7; i++) stp[(O_L + i) * Kp + kn] = dl[i];
+    }
+  }
+  wsync();
+  return ccl;
 }
 
 // ==============================================================================================================
@@ -307,10 +644,11 @@ __global__ __launch_bounds__(WAVE) void h_solve(const ascent_params *params, lon
   using L = Lay<0>;
   constexpr int NIT = L::NIT, R_ST = L::R_ST, R_KA = L::R_KA, R_K0 = L::R_K0, NROWS = L::NROWS;
   __shared__ double stage[H_ROWS * LDH];
-  __shared__ double lds_t[NPW][15][8];
+  __shared__ double lds_t[NPW][11][8];                   // transposes: rows 0-6 the column lanes, 7-10 the spare lanes
   __shared__ double lds_d[NPW][3][15];                  // (row 2 stays zero)
   __shared__ double lsc[NPW][NSCAL];
   __shared__ double lds_c[NPW][C_N];
+  __shared__ Der lds_der[NPW];                          // (read where it is used: the evaluations copy it, the sweeps do not hold it in registers)
   constexpr int CHN = WIDE ? HCW : HCH;                 // nodes per chunk
   const int lane = threadIdx.x, grp = lane >> 4, role = lane & 15;
   const int nl = WIDE ? lane : role;                    // this lane's node within a chunk ...
@@ -326,18 +664,22 @@ __global__ __launch_bounds__(WAVE) void h_solve(const ascent_params *params, lon
   double *gsc = w + (size_t)NROWS * Kp;
   double *sc = lsc[gi];
   double *carry = lds_c[gi];
-  const Der d = TERM == 2 ? derive_t(params[pc], 2) : derive(params[pc]);
+  if (role == 0) lds_der[gi] = TERM == 2 ? derive_t(params[pc], 2) : derive(params[pc]);
+  const Der *dp = &lds_der[gi];
+  const Der &d = *dp;
   for (int r = role; r < NSCAL; r += 16) sc[r] = gsc[r];
   if (role < 15) lds_d[grp][2][role] = 0.0;
   wsync();
   if (!live && role == 0) sc[X_STATE] = ST_DONE;
   wsync();
-  const double hT = (1.0 / K) * d.T;
+  const double hT = (1.0 / K) * dp->T;
   // lane roles of the factorisation sweep
   constexpr int RU = 7, RL = 8, RS = 11;                // the control's column; the first right-hand side; the first row of Lb Jb^-1 [Ja Ju]
   const bool col8 = role < 8, spare = role >= RS && role < RS + 4;
 
+  PROF_DECL
   for (int round = 0; round < 64 * (max_iter + 2); round++) {
+    PROF(9);
     // ============================ A: trial point, merit function and KKT error ======================================
     int state = (int)sc[X_STATE];
     if (__all(state == ST_DONE)) break;
@@ -354,13 +696,12 @@ __global__ __launch_bounds__(WAVE) void h_solve(const ascent_params *params, lon
         P.rd = sc[X_P + 0]; P.cinf = sc[X_P + 1]; P.pmin = sc[X_P + 2]; P.pmax = sc[X_P + 3]; P.l1 = sc[X_P + 4];
         P.zsum = sc[X_P + 5]; P.rth = sc[X_P + 6]; P.c1 = sc[X_P + 7]; P.sl = sc[X_P + 8]; P.mv = 0.0;
       } else {
-        TrialCtx t;
-        t.alpha = alpha; t.adu = adu; t.mlo = mu * 1e-10; t.mhi = mu * 1e10; t.dt = hT * stt.th; t.be = t.dt * d.alpha; t.hT = hT;
-        t.first = first; t.stt = stt; t.dcw = 0.0;
+        HsTrial t;
+        t.alpha = alpha; t.adu = adu; t.mu = mu; t.dt = hT * stt.th; t.hT = hT; t.first = first;
         P.clear();
         for (int c = nch - 1; c >= 0; c--) {
           const int k = c * CHN + nl;
-          hs_trial_chunk<TERM, WIDE>(d, K, Kp, k, nlane && k < K, nl, CHN, ic, stp, in, t, live, carry, P);
+          P = hs_trial_chunk<TERM>(dp, sc, K, Kp, k, nlane && k < K, nl == CHN - 1, nl == 0, ic, stp, in, t, live, carry, P);
         }
         P.template reduceW<0, WIDE>();
       }
@@ -424,6 +765,7 @@ __global__ __launch_bounds__(WAVE) void h_solve(const ascent_params *params, lon
       }
     }
     wsync();
+    PROF(0);
     // ============================ B: node blocks into LDS + backward factorisation ==================================
     state = (int)sc[X_STATE];
     if (__any(state == ST_FACTOR)) {
@@ -504,92 +846,13 @@ __global__ __launch_bounds__(WAVE) void h_solve(const ascent_params *params, lon
       }
       const bool probe_rows = sc[X_PROBE] == 2.0;
       for (int c = nch - 1; c >= 0 && !probe_rows; c--) {
-        // ---- node-parallel: the blocks of the steps of this chunk ------------------------------------------------------------
+        // ---- node-parallel: the blocks of the steps of this chunk (hs_eval_factor) -------------------------------------------
         {
           const int k = c * CHN + nl;
-          const bool on = nlane && k < K && act;
-          HsPts pt;
-          HsDual q;
-          double Hath[7] = {0, 0, 0, 0, 0, 0, 0}, Hbth[7], zb6[6], z[7], u = 0.0, lw = 0.0;
-          ASC_UNROLL
-          for (int i = 0; i < 7; i++) { q.ga[i] = 0.0; }
-          q.wa[0] = 0.0; q.wa[1] = 0.0;
-          if (on) {
-            double zp[7], l[7];
-            ASC_UNROLL
-            for (int i = 0; i < 7; i++) {
-              z[i] = it[(O_Z + i) * Kp + k]; zp[i] = k > 0 ? it[(O_Z + i) * Kp + k - 1] : 0.0; l[i] = it[(O_L + i) * Kp + k];
-            }
-            u = it[O_U * Kp + k]; lw = l[IW];
-            ASC_UNROLL
-            for (int b = 0; b < 6; b++) zb6[b] = it[(O_ZB + b) * Kp + k];
-            hs_points<1>(d, zp, z, u, h, l[IVX], l[IVY], pt);
-            hs_dual(pt, l, h, q);
-            double cc[7], Jth[7], Hthth;
-            hs_defect(pt, zp, z, h, hT, cc, Jth);
-            hs_theta(pt, q, h, hT, Hath, Hbth, Hthth);
-            hthth += Hthth;
-            double eb[4], es[4];
-            hs_blocks(pt.Gb, pt.Gm, h, eb, es);
-            const double sm = (4.0 / 6.0) * h;
-            ASC_UNROLL
-            for (int i = 0; i < 8; i++) {
-              stage[(H_GA + i) * LDH + col] = pt.Ga[i]; stage[(H_GM + i) * LDH + col] = pt.Gm[i]; stage[(H_GB + i) * LDH + col] = pt.Gb[i];
-            }
-            ASC_UNROLL
-            for (int i = 0; i < 4; i++) { stage[(H_EB + i) * LDH + col] = eb[i]; stage[(H_ES + i) * LDH + col] = es[i]; }
-            ASC_UNROLL
-            for (int i = 0; i < 10; i++) stage[(H_W + i) * LDH + col] = -sm * pt.Hm[i];
-            ASC_UNROLL
-            for (int i = 0; i < 7; i++) { stage[(H_C + i) * LDH + col] = cc[i]; stage[(H_JT + i) * LDH + col] = Jth[i]; }
-          }
-          // from the lane of step k+1 (or the carry of the chunk above): Ja'lambda, the theta column's entries on node k, the end-point weights
-          double gan[7], han[7], wan[2];
-          ASC_UNROLL
-          for (int i = 0; i < 7; i++) { gan[i] = __shfl_down(q.ga[i], 1); han[i] = __shfl_down(Hath[i], 1); }
-          wan[0] = __shfl_down(q.wa[0], 1); wan[1] = __shfl_down(q.wa[1], 1);
-          if (on) {
-            if (k == K - 1) {
-              ASC_UNROLL
-              for (int i = 0; i < 7; i++) { gan[i] = 0.0; han[i] = 0.0; }
-              wan[0] = 0.0; wan[1] = 0.0;
-            } else if (nl == CHN - 1) {
-              ASC_UNROLL
-              for (int i = 0; i < 7; i++) { gan[i] = carry[C_GA + i]; han[i] = carry[C_HA + i]; }
-              wan[0] = carry[C_WA]; wan[1] = carry[C_WA + 1];
-            }
-            double Hn[10], Gx[8], t1, t2;
-            accel<2>(d, z[IX], z[IY], z[IA], z[IM], q.wb[0] + wan[0], q.wb[1] + wan[1], t1, t2, Gx, Hn);
-            const double dist[6] = {z[IA], d.aub - z[IA], z[IM], 1.0 - z[IM], u + 1.0, 1.0 - u};
-            double id[6];
-            ASC_UNROLL
-            for (int b = 0; b < 6; b++) id[b] = rcp(dist[b]);
-            ASC_UNROLL
-            for (int i = 0; i < 10; i++) Hn[i] = -Hn[i];
-            Hn[7] += zb6[0] * id[0] + zb6[1] * id[1];
-            Hn[9] += zb6[2] * id[2] + zb6[3] * id[3];
-            ASC_UNROLL
-            for (int i = 0; i < 10; i++) stage[(H_H + i) * LDH + col] = Hn[i];
-            ASC_UNROLL
-            for (int i = 0; i < 7; i++) {
-              double rz = q.gb[i] + gan[i];
-              if (i == IA) rz += mu * (id[1] - id[0]);
-              if (i == IM) rz += mu * (id[3] - id[2]);
-              stage[(H_RZ + i) * LDH + col] = rz;
-              stage[(H_GT + i) * LDH + col] = Hbth[i] + han[i];
-            }
-            stage[H_R0 * LDH + col] = zb6[4] * id[4] + zb6[5] * id[5] + dw;
-            stage[(H_R0 + 1) * LDH + col] = -bu * lw + mu * (id[5] - id[4]);
-            stage[(H_R0 + 2) * LDH + col] = -hT * d.alpha * lw;
-          }
-          wsync();
-          if (on && nl == 0) {
-            ASC_UNROLL
-            for (int i = 0; i < 7; i++) { carry[C_GA + i] = q.ga[i]; carry[C_HA + i] = Hath[i]; }
-            carry[C_WA] = q.wa[0]; carry[C_WA + 1] = q.wa[1];
-          }
+          hthth += hs_eval_factor(dp, it, stage, carry, K, Kp, k, nlane && k < K && act, nl == CHN - 1, nl == 0, col, h, hT, mu, dw);
         }
         wsync();
+        PROF(1);
         // ---- serial: the steps of the chunk, backwards; 16 lanes per NLP -----------------------------------------------------
         if (act) {
           for (int jj = CHN - 1; jj >= 0; jj--) {
@@ -665,9 +928,9 @@ __global__ __launch_bounds__(WAVE) void h_solve(const ascent_params *params, lon
             hs_apply_j8t(J, b, m8);
             ASC_UNROLL
             for (int i = 0; i < 8; i++) m8[i] += laC[i];
-            if (role < 15) {
+            if (role < 7 || spare) {
               ASC_UNROLL
-              for (int i = 0; i < 8; i++) lds_t[grp][role][i] = m8[i];
+              for (int i = 0; i < 8; i++) lds_t[grp][role < 7 ? role : role - 4][i] = m8[i];
             }
             wsync();
             double a8[8];
@@ -680,7 +943,7 @@ __global__ __launch_bounds__(WAVE) void h_solve(const ascent_params *params, lon
               for (int i = 0; i < 8; i++) a8[i] = col8 ? o8[i] : m8[i];
               if (col8) {
                 ASC_UNROLL
-                for (int r = 0; r < 4; r++) xo[r] = lds_t[grp][RS + r][role];
+                for (int r = 0; r < 4; r++) xo[r] = lds_t[grp][7 + r][role];
               }
             }
             wsync();
@@ -708,6 +971,7 @@ __global__ __launch_bounds__(WAVE) void h_solve(const ascent_params *params, lon
           }
         }
         wsync();
+        PROF(2);
         // ---- flush the feedback gains of the chunk (node-parallel) ---------------------------------------------------------
         {
           const int k = c * CHN + nl;
@@ -725,6 +989,7 @@ __global__ __launch_bounds__(WAVE) void h_solve(const ascent_params *params, lon
           }
         }
         wsync();
+        PROF(3);
       }
       // ---- border: the 2x2 system in (theta, nu3); inertia ---------------------------------------------------------------------
       const double V0 = bcast16<RL>(V), U0 = bcast16<RL>(U), V1 = bcast16<RL + 1>(V), U1 = bcast16<RL + 1>(U), V2 = bcast16<RL + 2>(V), U2 = bcast16<RL + 2>(U);
@@ -786,7 +1051,7 @@ __global__ __launch_bounds__(WAVE) void h_solve(const ascent_params *params, lon
       // one row of a 6x6 matrix-vector product per lane and step (lanes 0-5: x y xdot ydot angle angledot, lane 6: du), the mass component a
       // prefix sum over the nodes -- the serial step of p_solve
       {
-        constexpr int NC = 6, FS = 7, F_OUT = 49;
+        constexpr int NC = 6, FS = 7;
         const int fbase = (role < 7 ? FS * role : 0) * LDH;
         const int fout = (F_OUT + (role < 6 ? role : role == 6 ? 7 : 8)) * LDH;     // out rows 0-5 dz, 6 dz_m (from the scan), 7 du, 8 dummy
         double yown = 0.0, carry_m = 0.0;
@@ -795,65 +1060,9 @@ __global__ __launch_bounds__(WAVE) void h_solve(const ascent_params *params, lon
         for (int c = 0; c < nch; c++) {
           const int kn = c * CHN + nl;
           const bool on = nlane && kn < K && act;
-          double a_ = 0.5, m_ = 0.5, u_ = 0.0, zb[6] = {1, 1, 1, 1, 1, 1};
-          double x0m = 0.0, du00 = 0.0, ka[7], rc[7];
-          HsJ J;
-          if (on) {
-            double z[7], zp[7];
-            ASC_UNROLL
-            for (int i = 0; i < 7; i++) { z[i] = it[(O_Z + i) * Kp + kn]; zp[i] = kn > 0 ? it[(O_Z + i) * Kp + kn - 1] : 0.0; }
-            u_ = it[O_U * Kp + kn];
-            a_ = z[IA]; m_ = z[IM];
-            ASC_UNROLL
-            for (int b = 0; b < 6; b++) zb[b] = it[(O_ZB + b) * Kp + kn];
-            ASC_UNROLL
-            for (int i = 0; i < 7; i++) ka[i] = w[(size_t)(R_KA + i) * Kp + kn];
-            du00 = -(w[(size_t)R_K0 * Kp + kn] + w[(size_t)(R_K0 + 1) * Kp + kn] * dth + w[(size_t)(R_K0 + 2) * Kp + kn] * dnu3);
-            HsPts pt;
-            hs_points<0>(d, zp, z, u_, h, 0.0, 0.0, pt);
-            double cc[7], Jth[7], eb[4], es[4];
-            hs_defect(pt, zp, z, h, hT, cc, Jth);
-            hs_blocks(pt.Gb, pt.Gm, h, eb, es);
-            hs_coeffs(pt.Ga, pt.Gm, pt.Gb, eb, es, h, bu, J);
-            ASC_UNROLL
-            for (int i = 0; i < 7; i++) rc[i] = cc[i] + Jth[i] * dth;
-            x0m = -rc[IM];
-          }
-          // dz_m: inclusive prefix sum of x0_m over the nodes of the NLP (the chunk here, the chunks before in carry_m)
-          double incl = x0m;
-          ASC_UNROLL
-          for (int sft = 1; sft < (WIDE ? 64 : 16); sft *= 2) {
-            const double t = __shfl_up(incl, sft, WIDE ? 64 : 16);
-            if (nl >= sft) incl += t;
-          }
-          const double dzm_k = carry_m + incl, dzm_p = dzm_k - x0m;
-          carry_m += WIDE ? __shfl(incl, HCW - 1) : bcast16<HCH - 1>(incl);
-          if (on) {
-            const double du00p = du00 - ka[IM] * dzm_p;
-            double X[4][7], Ab[4][7];
-            hs_rows(J, X, Ab);
-            auto emit = [&](int i, const double *xr_, const double *ar) {       // row i: its row of Jb^-1 and of Abar
-              const double bw = bu * xr_[IW];
-              double v = bw * du00p + ar[IM] * dzm_p;
-              ASC_UNROLL
-              for (int j = 0; j < 7; j++) v -= xr_[j] * rc[j];
-              ASC_UNROLL
-              for (int j = 0; j < 6; j++) stage[(FS * i + j) * LDH + col] = ar[j] - bw * ka[j];
-              stage[(FS * i + NC) * LDH + col] = v;
-            };
-            emit(IX, X[0], Ab[0]); emit(IY, X[1], Ab[1]); emit(IVX, X[2], Ab[2]); emit(IVY, X[3], Ab[3]);
-            {
-              const double xa[7] = {0, 0, 0, 0, 1.0, 0.5 * h, 0}, aa[7] = {0, 0, 0, 0, 1.0, h, 0};
-              emit(IA, xa, aa);
-              const double xw[7] = {0, 0, 0, 0, 0, 1.0, 0}, aw[7] = {0, 0, 0, 0, 0, 1.0, 0};
-              emit(IW, xw, aw);
-            }
-            ASC_UNROLL
-            for (int j = 0; j < 6; j++) stage[(42 + j) * LDH + col] = -ka[j];
-            stage[48 * LDH + col] = du00p;
-            stage[(F_OUT + 6) * LDH + col] = dzm_k;
-          }
+          carry_m = hs_eval_forward<WIDE>(dp, it, w + (size_t)R_KA * Kp, stage, K, Kp, kn, on, nl, col, h, hT, dth, dnu3, carry_m);
           wsync();
+          PROF(4);
           if (act) {
             const int jn = min(CHN, K - c * CHN);
             for (int jj = 0; jj < jn; jj++) {
@@ -868,11 +1077,15 @@ __global__ __launch_bounds__(WAVE) void h_solve(const ascent_params *params, lon
             }
           }
           wsync();
+          PROF(5);
           // ---- node-parallel: store the primal step, bound-multiplier steps, fraction to the boundary ----------------------
           if (on) {
-            double dzn[8];
+            double dzn[8], zb[6];
             ASC_UNROLL
             for (int i = 0; i < 8; i++) dzn[i] = stage[(F_OUT + i) * LDH + col];
+            const double a_ = it[(O_Z + IA) * Kp + kn], m_ = it[(O_Z + IM) * Kp + kn], u_ = it[O_U * Kp + kn];
+            ASC_UNROLL
+            for (int b = 0; b < 6; b++) zb[b] = it[(O_ZB + b) * Kp + kn];
             const double id[6] = {rcp(a_), rcp(d.aub - a_), rcp(m_), rcp(1.0 - m_), rcp(u_ + 1.0), rcp(1.0 - u_)};
             const double dza = dzn[IA], dzm = dzn[IM], du = dzn[7];
             if (kn == K - 1) cpy<7>(dzK, dzn);
@@ -899,6 +1112,7 @@ __global__ __launch_bounds__(WAVE) void h_solve(const ascent_params *params, lon
             }
           }
           wsync();
+          PROF(6);
         }
         rmax = gmaxW<WIDE>(rmax); gsum = gsumW<WIDE>(gsum); adu = gminW<WIDE>(adu);
         ASC_UNROLL
@@ -929,10 +1143,12 @@ __global__ __launch_bounds__(WAVE) void h_solve(const ascent_params *params, lon
         ASC_FTB(apr, s.s1, ds.s1); ASC_FTB(apr, s.s2, ds.s2);
         ASC_FTB(adu, s.zlt, ds.zlt); ASC_FTB(adu, s.zut, ds.zut);
         ASC_FTB(adu, s.zs1, ds.zs1); ASC_FTB(adu, s.zs2, ds.zs2);
-        TrialCtx tc;
-        tc.alpha = apr; tc.adu = adu; tc.mlo = mu * 1e-10; tc.mhi = mu * 1e10; tc.hT = hT; tc.first = false; tc.dcw = 0.0;
-        tc.stt = trial_scal(d, s, ds, apr, adu, mu, false);
-        tc.dt = hT * tc.stt.th; tc.be = tc.dt * d.alpha;
+        HsTrial tc;
+        tc.alpha = apr; tc.adu = adu; tc.mu = mu; tc.hT = hT; tc.first = false;
+        tc.dt = hT * trial_scal(d, s, ds, apr, adu, mu, false).th;
+        wsync();
+        if (role == 0 && act) put_scal(sc, X_D, ds);      // (the trial point's scalars are formed from the record: iterate X_S, step X_D)
+        wsync();
         double *in = w + (size_t)((1 - (int)sc[X_CUR]) * NIT) * Kp;
         Part P;
         P.clear();
@@ -940,137 +1156,18 @@ __global__ __launch_bounds__(WAVE) void h_solve(const ascent_params *params, lon
         // With psi_k = -Ja_{k+1}' dlam_{k+1} the stationarity row of node k reads Jb_k' dlam_k = psi_k - rhs_k (rhs_k: everything the forward
         // sweep has fixed), and psi_{k-1} = Abar_k' (psi_k - rhs_k): affine in psi with node-local coefficients.  Columns angledot and mass of
         // Abar' are unit vectors and column angle is e_a + h e_w: the serial step of p_solve (five coefficients, the lane's own value, w).
-        constexpr int A_OUT = 42;
         const int abase = (role < 7 ? 6 * role : 0) * LDH;
-        const int aout = (A_OUT + (role < 7 ? role : 8)) * LDH;
+        const int aout = (role < 7 ? role : 8) * LDH;         // psi_{k-1} over the consumed coefficient rows 0-6 of the column (8: dummy)
         const double aself = (role == IW || role == IM) ? 1.0 : 0.0;
         double lown = 0.0;
         double cl = 0.0, ccl = 0.0;
         for (int c = nch - 1; c >= 0; c--) {
           const int kn = c * CHN + nl;
           const bool on = nlane && kn < K && act;
-          double ccn[7] = {0, 0, 0, 0, 0, 0, 0}, rhs[7] = {0, 0, 0, 0, 0, 0, 0};
-          double om[4] = {0, 0, 0, 0}, Hath[7] = {0, 0, 0, 0, 0, 0, 0}, Hbth[7];
-          HsJ J;
-          HsPts pt;
-          HsDual q;
-          ASC_UNROLL
-          for (int i = 0; i < 7; i++) q.ga[i] = 0.0;
-          q.wa[0] = 0.0; q.wa[1] = 0.0;
-          double z[7], dz[7], zb6[6];
-          if (on) {
-            double zp[7], l[7], dzp[7];
-            ASC_UNROLL
-            for (int i = 0; i < 7; i++) {
-              z[i] = it[(O_Z + i) * Kp + kn]; zp[i] = kn > 0 ? it[(O_Z + i) * Kp + kn - 1] : 0.0; l[i] = it[(O_L + i) * Kp + kn];
-              dz[i] = stp[(O_Z + i) * Kp + kn]; dzp[i] = kn > 0 ? stp[(O_Z + i) * Kp + kn - 1] : 0.0;
-            }
-            const double u = it[O_U * Kp + kn];
-            ASC_UNROLL
-            for (int b = 0; b < 4; b++) zb6[b] = it[(O_ZB + b) * Kp + kn];
-            hs_points<1>(d, zp, z, u, h, l[IVX], l[IVY], pt);
-            hs_dual(pt, l, h, q);
-            double Jth[7], Hthth, eb[4], es[4];
-            hs_defect(pt, zp, z, h, hT, ccn, Jth);
-            hs_theta(pt, q, h, hT, Hath, Hbth, Hthth);
-            hs_blocks(pt.Gb, pt.Gm, h, eb, es);
-            hs_coeffs(pt.Ga, pt.Gm, pt.Gb, eb, es, h, bu, J);
-            ASC_UNROLL
-            for (int i = 0; i < 7; i++) ccl += ccn[i] * l[i];
-            // omega = W (La dz_{k-1} + Lb dz_k) on (x, y, angle, mass)
-            const double xi[4] = {0.5 * (dzp[IX] + dz[IX]) + e8 * (dzp[IVX] - dz[IVX]), 0.5 * (dzp[IY] + dz[IY]) + e8 * (dzp[IVY] - dz[IVY]),
-                                  0.5 * (dzp[IA] + dz[IA]) + e8 * (dzp[IW] - dz[IW]), 0.5 * (dzp[IM] + dz[IM])};
-            const double sm = (4.0 / 6.0) * h;
-            const double *H = pt.Hm;
-            om[0] = -sm * (H[0] * xi[0] + H[1] * xi[1] + H[2] * xi[2] + H[3] * xi[3]);
-            om[1] = -sm * (H[1] * xi[0] + H[4] * xi[1] + H[5] * xi[2] + H[6] * xi[3]);
-            om[2] = -sm * (H[2] * xi[0] + H[5] * xi[1] + H[7] * xi[2] + H[8] * xi[3]);
-            om[3] = -sm * (H[3] * xi[0] + H[6] * xi[1] + H[8] * xi[2] + H[9] * xi[3]);
-          }
-          double gan[7], han[7], wan[2], omn[4];
-          ASC_UNROLL
-          for (int i = 0; i < 7; i++) { gan[i] = __shfl_down(q.ga[i], 1); han[i] = __shfl_down(Hath[i], 1); }
-          wan[0] = __shfl_down(q.wa[0], 1); wan[1] = __shfl_down(q.wa[1], 1);
-          ASC_UNROLL
-          for (int r = 0; r < 4; r++) omn[r] = __shfl_down(om[r], 1);
-          if (on) {
-            if (kn == K - 1) {
-              ASC_UNROLL
-              for (int i = 0; i < 7; i++) { gan[i] = 0.0; han[i] = 0.0; }
-              wan[0] = 0.0; wan[1] = 0.0;
-              ASC_UNROLL
-              for (int r = 0; r < 4; r++) omn[r] = 0.0;
-            } else if (nl == CHN - 1) {
-              ASC_UNROLL
-              for (int i = 0; i < 7; i++) { gan[i] = carry[C_GA + i]; han[i] = carry[C_HA + i]; }
-              wan[0] = carry[C_WA]; wan[1] = carry[C_WA + 1];
-              ASC_UNROLL
-              for (int r = 0; r < 4; r++) omn[r] = carry[C_OM + r];
-            }
-            double Hn[10], Gx[8], t1, t2;
-            accel<2>(d, z[IX], z[IY], z[IA], z[IM], q.wb[0] + wan[0], q.wb[1] + wan[1], t1, t2, Gx, Hn);
-            const double id0 = rcp(z[IA]), id1 = rcp(d.aub - z[IA]), id2 = rcp(z[IM]), id3 = rcp(1.0 - z[IM]);
-            ASC_UNROLL
-            for (int i = 0; i < 10; i++) Hn[i] = -Hn[i];
-            Hn[7] += zb6[0] * id0 + zb6[1] * id1;
-            Hn[9] += zb6[2] * id2 + zb6[3] * id3;
-            ASC_UNROLL
-            for (int i = 0; i < 7; i++) rhs[i] = (q.gb[i] + gan[i]) + (Hbth[i] + han[i]) * dth + dw * dz[i];
-            rhs[IA] += mu * (id1 - id0);
-            rhs[IM] += mu * (id3 - id2);
-            rhs[IX] += Hn[0] * dz[IX] + Hn[1] * dz[IY] + Hn[2] * dz[IA] + Hn[3] * dz[IM];
-            rhs[IY] += Hn[1] * dz[IX] + Hn[4] * dz[IY] + Hn[5] * dz[IA] + Hn[6] * dz[IM];
-            rhs[IA] += Hn[2] * dz[IX] + Hn[5] * dz[IY] + Hn[7] * dz[IA] + Hn[8] * dz[IM];
-            rhs[IM] += Hn[3] * dz[IX] + Hn[6] * dz[IY] + Hn[8] * dz[IA] + Hn[9] * dz[IM];
-            // the midpoint terms: Lb_k' omega_k + La_{k+1}' omega_{k+1}
-            rhs[IX] += 0.5 * (om[0] + omn[0]); rhs[IY] += 0.5 * (om[1] + omn[1]); rhs[IA] += 0.5 * (om[2] + omn[2]); rhs[IM] += 0.5 * (om[3] + omn[3]);
-            rhs[IVX] += e8 * (omn[0] - om[0]); rhs[IVY] += e8 * (omn[1] - om[1]); rhs[IW] += e8 * (omn[2] - om[2]);
-            if (kn == K - 1) {
-              double QT[28], qd[7];
-              const Terminal tm = TERM == 2 ? terminal_eval_any(d, z) : terminal_eval(d, z);
-              ASC_UNROLL
-              for (int i = 0; i < 28; i++) QT[i] = 0.0;
-              if constexpr (TERM == 2) terminal_hessian_any(QT, tm, s.nu1, s.nu2, sig1, sig2);
-              else terminal_hessian(QT, tm, s.nu3, s.nu1, s.nu2, sig1, sig2);
-              symv(QT, dz, qd);
-              ASC_UNROLL
-              for (int i = 0; i < 7; i++) rhs[i] += qd[i];
-              const double w1 = s.nu1 + sig1 * sc[X_CG1] + rs1, w2 = s.nu2 + sig2 * sc[X_CG2] + rs2;
-              if constexpr (TERM == 2) {
-                double g4[4];
-                terminal_grad_any(tm, w1, w2, g4);
-                rhs[IX] += g4[0]; rhs[IY] += g4[1]; rhs[IVX] += g4[2]; rhs[IVY] += g4[3];
-              } else {
-                rhs[IX] += s.nu3 * tm.e3g[0] + w1 * tm.g1g[0] + tm.e3g[0] * dnu3;
-                rhs[IY] += s.nu3 * tm.e3g[1] + w1 * tm.g1g[1] + tm.e3g[1] * dnu3;
-                rhs[IVX] += s.nu3 * tm.e3g[2] + w2 * tm.g2g[0] + tm.e3g[2] * dnu3;
-                rhs[IVY] += s.nu3 * tm.e3g[3] + w2 * tm.g2g[1] + tm.e3g[3] * dnu3;
-              }
-            }
-            // coefficients: column j = x, y, xdot, ydot of Abar' is row j of Abar; column angle is e_a + h e_w; w = -Abar' rhs = Ja' Jb^-T rhs
-            double X[4][7], Ab[4][7];
-            hs_rows(J, X, Ab);
-            double xs[7], o8[8];
-            hs_solve_jbt(J, rhs, xs);
-            hs_apply_j8t(J, xs, o8);
-            ASC_UNROLL
-            for (int i = 0; i < 7; i++) {
-              ASC_UNROLL
-              for (int j = 0; j < 4; j++) stage[(6 * i + j) * LDH + col] = Ab[j][i];
-              stage[(6 * i + 4) * LDH + col] = i == IA ? 1.0 : i == IW ? h : 0.0;
-              stage[(6 * i + 5) * LDH + col] = -o8[i];
-            }
-          }
-          wsync();
-          if (on && nl == 0) {
-            ASC_UNROLL
-            for (int i = 0; i < 7; i++) { carry[C_GA + i] = q.ga[i]; carry[C_HA + i] = Hath[i]; }
-            carry[C_WA] = q.wa[0]; carry[C_WA + 1] = q.wa[1];
-            ASC_UNROLL
-            for (int r = 0; r < 4; r++) carry[C_OM + r] = om[r];
-          }
+          ccl += hs_eval_adjoint<TERM>(dp, sc, it, stp, stage, carry, K, Kp, kn, on, nl == CHN - 1, nl == 0, col, h, hT, mu, dw, dth, dnu3);
           if (role < 7) carry[C_PSI + role] = lown;            // psi of the chunk's last node: what the sweep of the chunk above has left
           wsync();
+          PROF(7);
           if (act) {
             const int jj0 = min(CHN, K - c * CHN) - 1;
             for (int jj = jj0; jj >= 0; jj--) {
@@ -1084,24 +1181,11 @@ __global__ __launch_bounds__(WAVE) void h_solve(const ascent_params *params, lon
             }
           }
           wsync();
-          if (on) {
-            double ph[7], dl[7];
-            ASC_UNROLL
-            for (int i = 0; i < 7; i++) {
-              const double psi = kn + 1 < K ? (nl < CHN - 1 ? stage[(A_OUT + i) * LDH + col + 1] : carry[C_PSI + i]) : 0.0;
-              ph[i] = psi - rhs[i];
-            }
-            hs_solve_jbt(J, ph, dl);
-            ASC_UNROLL
-            for (int i = 0; i < 7; i++) ccl += ccn[i] * dl[i];            // c . dlambda: no recurrence, summed here
-            if (live) {
-              ASC_UNROLL
-              for (int i = 0; i < 7; i++) stp[(O_L + i) * Kp + kn] = dl[i];
-            }
-          }
-          wsync();
+          PROF(8);
+          ccl += hs_post_adjoint(stage, carry, stp, K, Kp, kn, on, nl == CHN - 1, col, h, live);
           // ---- the step of the chunk is complete: its trial point at the first step length ---------------------------------------------
-          hs_trial_chunk<TERM, WIDE>(d, K, Kp, kn, on, nl, CHN, it, stp, in, tc, live, carry, P);
+          P = hs_trial_chunk<TERM>(dp, sc, K, Kp, kn, on, nl == CHN - 1, nl == 0, it, stp, in, tc, live, carry, P);
+          PROF(0);
         }
         P.template reduceW<0, WIDE>();
         // ---- scalars of the step, merit bookkeeping -------------------------------------------------------------------------
@@ -1121,7 +1205,6 @@ __global__ __launch_bounds__(WAVE) void h_solve(const ascent_params *params, lon
           }
           wsync();
           if (role == 0) {
-            put_scal(sc, X_D, ds);
             sc[X_NUP] = nu_pen;
             sc[X_DM] = gd - nu_pen * c1;
             sc[X_PHI0] = s.th - mu * slog + nu_pen * c1;
@@ -1138,6 +1221,7 @@ __global__ __launch_bounds__(WAVE) void h_solve(const ascent_params *params, lon
     if (sc[X_PROBE] != 0.0) break;
   }
   wsync();
+  PROF_END;
   if (live)
     for (int r = role; r < NSCAL; r += 16) gsc[r] = sc[r];
 }

@@ -500,15 +500,6 @@ ASC_DEV void trial_node(const Der &d, int K, int Kp, int k, const NodeIn &n, con
   trial_dual<SCHEME, FORM, MP, TERM>(d, K, Kp, k, kp, l, ln, lu, lun, t, live, in, P);
 }
 
-#ifdef PERSIST_PROFILE      // diagnostic build (scripts/persist_profile.py): shader cycles per phase, wavefront 0
-#define PROF_DECL long long prof_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long pt_ = clock64();
-#define PROF(i_) do { const long long t1_ = clock64(); prof_[i_] += t1_ - pt_; pt_ = t1_; } while (0)
-#define PROF_END do { if (blockIdx.x == 0 && threadIdx.x == 0) printf("[persist profile] cycles: A %lld | B eval %lld serial %lld flush %lld | F eval %lld serial %lld post %lld | Adj eval %lld serial %lld | rest %lld\n", prof_[0], prof_[1], prof_[2], prof_[3], prof_[4], prof_[5], prof_[6], prof_[7], prof_[8], prof_[9]); } while (0)
-#else
-#define PROF_DECL
-#define PROF(i_) do { } while (0)
-#define PROF_END do { } while (0)
-#endif
 
 template <int SCHEME, int FORM, int MP = 0, int TERM = 0, int WIDE = 0>
 __global__ __launch_bounds__(WAVE) void p_solve(const ascent_params *params, long batch, PGeo g, double *ws, int max_iter, double tol) {

@@ -159,4 +159,14 @@ struct TrialCtx {       // what the trial point of an NLP needs besides the node
   Scal stt;
 };
 
+#ifdef PERSIST_PROFILE      // diagnostic build (scripts/persist_profile.py): shader cycles per phase, wavefront 0
+#define PROF_DECL long long prof_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; long long pt_ = clock64();
+#define PROF(i_) do { const long long t1_ = clock64(); prof_[i_] += t1_ - pt_; pt_ = t1_; } while (0)
+#define PROF_END do { if (blockIdx.x == 0 && threadIdx.x == 0) printf("[persist profile] cycles: A %lld | B eval %lld serial %lld flush %lld | F eval %lld serial %lld post %lld | Adj eval %lld serial %lld | rest %lld\n", prof_[0], prof_[1], prof_[2], prof_[3], prof_[4], prof_[5], prof_[6], prof_[7], prof_[8], prof_[9]); } while (0)
+#else
+#define PROF_DECL
+#define PROF(i_) do { } while (0)
+#define PROF_END do { } while (0)
+#endif
+
 }  // namespace
