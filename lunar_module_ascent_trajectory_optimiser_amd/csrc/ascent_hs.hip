@@ -40,6 +40,8 @@ using namespace ascent;
 
 namespace {
 
+typedef __attribute__((address_space(3))) double ldbl;      // LDS double (the functions below take their pointers with address spaces:
+                                                             // generic pointers would make every access a flat instruction)
 constexpr int HCH = 12, HCW = 48;     // nodes per chunk: four NLPs x 12, or one NLP x 48 (the LDS stage has 48 columns)
 constexpr int LDH = 49;               // row stride of the stage in doubles (odd: the rows a sweep step gathers hit different banks)
 // stage rows of the factorisation phase (one chunk)
@@ -47,6 +49,21 @@ constexpr int H_GA = 0, H_GM = 8, H_GB = 16, H_EB = 24, H_ES = 28, H_W = 32, H_R
               H_GT = 76, H_ROWS = 83;
 // carry between chunks (descending order): what the last node of a chunk needs of the first step of the chunk above
 constexpr int C_PSI = 0, C_GA = 7, C_HA = 14, C_WA = 21, C_OM = 23, C_TG = 27, C_N = 34;   // (C_TG: Ja'lambda of the TRIAL point)
+
+
+// Der in LDS (16 doubles): the evaluations copy it into registers, the sweeps read single fields
+constexpr int DER_N = 16;
+ASC_DEV void der_store(double *p, const Der &d) {
+  p[0] = d.rho0; p[1] = d.rhof; p[2] = d.vp2; p[3] = d.gam; p[4] = d.thr; p[5] = d.alpha; p[6] = d.mrate; p[7] = d.ms; p[8] = d.M0; p[9] = d.T;
+  p[10] = d.aub; p[11] = d.tlb; p[12] = d.tub; p[13] = (double)d.term; p[14] = d.ht; p[15] = d.Et;
+}
+template <typename PT>
+ASC_DEV Der der_load(PT p) {
+  Der d;
+  d.rho0 = p[0]; d.rhof = p[1]; d.vp2 = p[2]; d.gam = p[3]; d.thr = p[4]; d.alpha = p[5]; d.mrate = p[6]; d.ms = p[7]; d.M0 = p[8]; d.T = p[9];
+  d.aub = p[10]; d.tlb = p[11]; d.tub = p[12]; d.term = (int)p[13]; d.ht = p[14]; d.Et = p[15];
+  return d;
+}
 
 // ---- the three evaluation points of a step -------------------------------------------------------------------------------------
 struct HsPts { double Ga[8], Gb[8], Gm[8], fa[7], fb[7], fm[7], Hm[10]; };
@@ -203,9 +220,9 @@ ASC_DEV void hs_rows(const HsJ &J, double X[4][7], double Ab[4][7]) {
 //  come from the NLP's record in LDS: iterate X_S, step X_D.)
 struct HsTrial { double alpha, adu, mu, dt, hT; bool first; };
 template <int TERM>
-ASC_PASS Part hs_trial_chunk(const Der *dp, const double *sc, int K, int Kp, int k, bool on, bool lastl, bool firstl, const double *ic, const double *stp,
-                             double *in, HsTrial t, bool live, double *carry, Part P) {
-  const Der d = *dp;
+ASC_PASS Part hs_trial_chunk(const ldbl *dp, const ldbl *sc, int K, int Kp, int k, bool on, bool lastl, bool firstl, const gdbl *ic, const gdbl *stp,
+                             gdbl *in, HsTrial t, bool live, ldbl *carry, Part P) {
+  const Der d = der_load(dp);
   const double be = t.dt * d.alpha, mlo = t.mu * 1e-10, mhi = t.mu * 1e10;
   double ga[7] = {0, 0, 0, 0, 0, 0, 0}, r[7] = {0, 0, 0, 0, 0, 0, 0};
   if (on) {
@@ -313,9 +330,9 @@ ASC_PASS Part hs_trial_chunk(const Der *dp, const double *sc, int K, int Kp, int
 // around the call in one burst.  Lane = node k (step k: nodes k-1, k); lastl / firstl: the last / first node of the chunk.
 
 // Factorisation phase: the step's blocks into the LDS stage (column col).  Returns the step's part of the (theta, theta) entry.
-ASC_PASS double hs_eval_factor(const Der *dp, const double *it, double *stage, double *carry, int K, int Kp, int k, bool on, bool lastl, bool firstl,
+ASC_PASS double hs_eval_factor(const ldbl *dp, const gdbl *it, ldbl *stage, ldbl *carry, int K, int Kp, int k, bool on, bool lastl, bool firstl,
                                int col, double h, double hT, double mu, double dw) {
-  const Der d = *dp;
+  const Der d = der_load(dp);
   const double bu = h * d.alpha;
   HsPts pt;
   HsDual q;
@@ -404,9 +421,9 @@ ASC_PASS double hs_eval_factor(const Der *dp, const double *it, double *stage, d
 // stage, the mass component by a prefix sum over the nodes (row F_OUT + 6).  carry_m: dz_m of the last node of the chunk before; returns the new one.
 constexpr int F_OUT = 49, A_RHS = 42, A_C = 49, A_J = 56;      // (adjoint: rhs, defect and the coefficients of Jb stashed beside the recursion's rows)
 template <int WIDE>
-ASC_PASS double hs_eval_forward(const Der *dp, const double *it, const double *gains, double *stage, int K, int Kp, int kn, bool on, int nl, int col,
+ASC_PASS double hs_eval_forward(const ldbl *dp, const gdbl *it, const gdbl *gains, ldbl *stage, int K, int Kp, int kn, bool on, int nl, int col,
                                 double h, double hT, double dth, double dnu3, double carry_m) {
-  const Der d = *dp;
+  const Der d = der_load(dp);
   const double bu = h * d.alpha;
   double x0m = 0.0, du00 = 0.0, ka[7], rc[7];
   HsJ J;
@@ -471,9 +488,9 @@ ASC_PASS double hs_eval_forward(const Der *dp, const double *it, const double *g
 // psi_{k-1} = Abar_k' (psi_k - rhs_k) into rows 6 i .. 6 i + 5 of the stage, and -- for the part after the sweep -- rhs, the defect and the
 // coefficients of Jb into rows A_RHS / A_C / A_J of the lane's column.  Returns c . lambda of the node.
 template <int TERM>
-ASC_PASS double hs_eval_adjoint(const Der *dp, const double *sc, const double *it, const double *stp, double *stage, double *carry, int K, int Kp, int kn,
+ASC_PASS double hs_eval_adjoint(const ldbl *dp, const ldbl *sc, const gdbl *it, const gdbl *stp, ldbl *stage, ldbl *carry, int K, int Kp, int kn,
                                 bool on, bool lastl, bool firstl, int col, double h, double hT, double mu, double dw, double dth, double dnu3) {
-  const Der d = *dp;
+  const Der d = der_load(dp);
   const double bu = h * d.alpha, e8 = 0.125 * h;
   double ccl = 0.0, ccn[7], rhs[7] = {0, 0, 0, 0, 0, 0, 0};
   double om[4] = {0, 0, 0, 0}, Hath[7] = {0, 0, 0, 0, 0, 0, 0}, Hbth[7];
@@ -606,7 +623,7 @@ ASC_PASS double hs_eval_adjoint(const Der *dp, const double *sc, const double *i
   return ccl;
 }
 // ... and after the sweep: Jb_k' dlam_k = psi_k - rhs_k (psi: rows 0-6 of the next column, or the carry at the end of a chunk); returns c . dlambda
-ASC_PASS double hs_post_adjoint(double *stage, const double *carry, double *stp, int K, int Kp, int kn, bool on, bool lastl, int col, double h, bool live) {
+ASC_PASS double hs_post_adjoint(ldbl *stage, const ldbl *carry, gdbl *stp, int K, int Kp, int kn, bool on, bool lastl, int col, double h, bool live) {
   double ccl = 0.0;
   if (on) {
     HsJ J;
@@ -648,7 +665,7 @@ __global__ __launch_bounds__(WAVE) void h_solve(const ascent_params *params, lon
   __shared__ double lds_d[NPW][3][15];                  // (row 2 stays zero)
   __shared__ double lsc[NPW][NSCAL];
   __shared__ double lds_c[NPW][C_N];
-  __shared__ Der lds_der[NPW];                          // (read where it is used: the evaluations copy it, the sweeps do not hold it in registers)
+  __shared__ double lds_der[NPW][DER_N];                // (the evaluations copy it into registers of their own)
   constexpr int CHN = WIDE ? HCW : HCH;                 // nodes per chunk
   const int lane = threadIdx.x, grp = lane >> 4, role = lane & 15;
   const int nl = WIDE ? lane : role;                    // this lane's node within a chunk ...
@@ -664,15 +681,17 @@ __global__ __launch_bounds__(WAVE) void h_solve(const ascent_params *params, lon
   double *gsc = w + (size_t)NROWS * Kp;
   double *sc = lsc[gi];
   double *carry = lds_c[gi];
-  if (role == 0) lds_der[gi] = TERM == 2 ? derive_t(params[pc], 2) : derive(params[pc]);
-  const Der *dp = &lds_der[gi];
-  const Der &d = *dp;
+  const Der d = TERM == 2 ? derive_t(params[pc], 2) : derive(params[pc]);
+  if (role == 0) der_store(lds_der[gi], d);
+  const ldbl *dp = (const ldbl *)lds_der[gi];
+  ldbl *lstage = (ldbl *)stage, *lcarry = (ldbl *)carry;
+  const ldbl *lsc_ = (const ldbl *)sc;
   for (int r = role; r < NSCAL; r += 16) sc[r] = gsc[r];
   if (role < 15) lds_d[grp][2][role] = 0.0;
   wsync();
   if (!live && role == 0) sc[X_STATE] = ST_DONE;
   wsync();
-  const double hT = (1.0 / K) * dp->T;
+  const double hT = (1.0 / K) * d.T;
   // lane roles of the factorisation sweep
   constexpr int RU = 7, RL = 8, RS = 11;                // the control's column; the first right-hand side; the first row of Lb Jb^-1 [Ja Ju]
   const bool col8 = role < 8, spare = role >= RS && role < RS + 4;
@@ -701,7 +720,7 @@ __global__ __launch_bounds__(WAVE) void h_solve(const ascent_params *params, lon
         P.clear();
         for (int c = nch - 1; c >= 0; c--) {
           const int k = c * CHN + nl;
-          P = hs_trial_chunk<TERM>(dp, sc, K, Kp, k, nlane && k < K, nl == CHN - 1, nl == 0, ic, stp, in, t, live, carry, P);
+          P = hs_trial_chunk<TERM>(dp, lsc_, K, Kp, k, nlane && k < K, nl == CHN - 1, nl == 0, (const gdbl *)ic, (const gdbl *)stp, (gdbl *)in, t, live, lcarry, P);
         }
         P.template reduceW<0, WIDE>();
       }
@@ -849,7 +868,7 @@ __global__ __launch_bounds__(WAVE) void h_solve(const ascent_params *params, lon
         // ---- node-parallel: the blocks of the steps of this chunk (hs_eval_factor) -------------------------------------------
         {
           const int k = c * CHN + nl;
-          hthth += hs_eval_factor(dp, it, stage, carry, K, Kp, k, nlane && k < K && act, nl == CHN - 1, nl == 0, col, h, hT, mu, dw);
+          hthth += hs_eval_factor(dp, (const gdbl *)it, lstage, lcarry, K, Kp, k, nlane && k < K && act, nl == CHN - 1, nl == 0, col, h, hT, mu, dw);
         }
         wsync();
         PROF(1);
@@ -1060,7 +1079,7 @@ __global__ __launch_bounds__(WAVE) void h_solve(const ascent_params *params, lon
         for (int c = 0; c < nch; c++) {
           const int kn = c * CHN + nl;
           const bool on = nlane && kn < K && act;
-          carry_m = hs_eval_forward<WIDE>(dp, it, w + (size_t)R_KA * Kp, stage, K, Kp, kn, on, nl, col, h, hT, dth, dnu3, carry_m);
+          carry_m = hs_eval_forward<WIDE>(dp, (const gdbl *)it, (const gdbl *)(w + (size_t)R_KA * Kp), lstage, K, Kp, kn, on, nl, col, h, hT, dth, dnu3, carry_m);
           wsync();
           PROF(4);
           if (act) {
@@ -1164,7 +1183,7 @@ __global__ __launch_bounds__(WAVE) void h_solve(const ascent_params *params, lon
         for (int c = nch - 1; c >= 0; c--) {
           const int kn = c * CHN + nl;
           const bool on = nlane && kn < K && act;
-          ccl += hs_eval_adjoint<TERM>(dp, sc, it, stp, stage, carry, K, Kp, kn, on, nl == CHN - 1, nl == 0, col, h, hT, mu, dw, dth, dnu3);
+          ccl += hs_eval_adjoint<TERM>(dp, lsc_, (const gdbl *)it, (const gdbl *)stp, lstage, lcarry, K, Kp, kn, on, nl == CHN - 1, nl == 0, col, h, hT, mu, dw, dth, dnu3);
           if (role < 7) carry[C_PSI + role] = lown;            // psi of the chunk's last node: what the sweep of the chunk above has left
           wsync();
           PROF(7);
@@ -1182,9 +1201,9 @@ __global__ __launch_bounds__(WAVE) void h_solve(const ascent_params *params, lon
           }
           wsync();
           PROF(8);
-          ccl += hs_post_adjoint(stage, carry, stp, K, Kp, kn, on, nl == CHN - 1, col, h, live);
+          ccl += hs_post_adjoint(lstage, lcarry, (gdbl *)stp, K, Kp, kn, on, nl == CHN - 1, col, h, live);
           // ---- the step of the chunk is complete: its trial point at the first step length ---------------------------------------------
-          P = hs_trial_chunk<TERM>(dp, sc, K, Kp, kn, on, nl == CHN - 1, nl == 0, it, stp, in, tc, live, carry, P);
+          P = hs_trial_chunk<TERM>(dp, lsc_, K, Kp, kn, on, nl == CHN - 1, nl == 0, (const gdbl *)it, (const gdbl *)stp, (gdbl *)in, tc, live, lcarry, P);
           PROF(0);
         }
         P.template reduceW<0, WIDE>();

@@ -88,7 +88,8 @@ template <int WIDE> ASC_DEV double gsumW(double v) { v = gsum16(v); if constexpr
 template <int WIDE> ASC_DEV double gmaxW(double v) { v = gmax16(v); if constexpr (WIDE) { v = fmax(v, __shfl_xor(v, 16)); v = fmax(v, __shfl_xor(v, 32)); } return v; }
 template <int WIDE> ASC_DEV double gminW(double v) { v = gmin16(v); if constexpr (WIDE) { v = fmin(v, __shfl_xor(v, 16)); v = fmin(v, __shfl_xor(v, 32)); } return v; }
 
-ASC_DEV Scal lds_scal(const double *sc, int r0) {
+template <typename PT>      // (a generic or an LDS pointer)
+ASC_DEV Scal lds_scal(PT sc, int r0) {
   Scal s;
   s.th = sc[r0 + S_TH]; s.zlt = sc[r0 + S_ZLT]; s.zut = sc[r0 + S_ZUT]; s.s1 = sc[r0 + S_S1]; s.s2 = sc[r0 + S_S2];
   s.zs1 = sc[r0 + S_ZS1]; s.zs2 = sc[r0 + S_ZS2]; s.nu3 = sc[r0 + S_NU3]; s.nu1 = sc[r0 + S_NU1]; s.nu2 = sc[r0 + S_NU2];
