@@ -219,18 +219,30 @@ ASC_DEV void hs_rows(const HsJ &J, double X[4][7], double Ab[4][7]) {
 // (A function of its own -- one register allocation per node-parallel evaluation, see hs_eval_factor below; the scalars of the trial point
 //  come from the NLP's record in LDS: iterate X_S, step X_D.)
 struct HsTrial { double alpha, adu, mu, dt, hT; bool first; };
+#ifdef PERSIST_PROFILE
+__device__ unsigned long long g_hsprof[8];
+#define HPROF(i_) do { __builtin_amdgcn_sched_barrier(0); const long long t1_ = clock64(); if (blockIdx.x == 0 && threadIdx.x == 0) g_hsprof[i_] += t1_ - hp_; hp_ = t1_; __builtin_amdgcn_sched_barrier(0); } while (0)
+#define HPROF_DECL long long hp_ = clock64();
+#else
+#define HPROF(i_) do { } while (0)
+#define HPROF_DECL
+#endif
 template <int TERM>
 ASC_PASS Part hs_trial_chunk(const ldbl *dp, const ldbl *sc, int K, int Kp, int k, bool on, bool lastl, bool firstl, const gdbl *ic, const gdbl *stp,
                              gdbl *in, HsTrial t, bool live, ldbl *carry, Part P) {
+  HPROF_DECL
   const Der d = der_load(dp);
   const double be = t.dt * d.alpha, mlo = t.mu * 1e-10, mhi = t.mu * 1e10;
   double ga[7] = {0, 0, 0, 0, 0, 0, 0}, r[7] = {0, 0, 0, 0, 0, 0, 0};
   if (on) {
     const double alpha = t.alpha;
+    const int km = k > 0 ? k - 1 : 0;
     double z[7], zp[7], l[7], zb[6];
     ASC_UNROLL
     for (int i = 0; i < 7; i++) {
-      z[i] = ic[(O_Z + i) * Kp + k]; zp[i] = k > 0 ? ic[(O_Z + i) * Kp + k - 1] : 0.0; l[i] = ic[(O_L + i) * Kp + k];
+      z[i] = ic[(O_Z + i) * Kp + k]; l[i] = ic[(O_L + i) * Kp + k];
+      const double pv = ic[(O_Z + i) * Kp + km];      // (node k-1 by a clamped index and a select: a conditional load is a branch and a wait each)
+      zp[i] = k > 0 ? pv : 0.0;
     }
     double u = ic[O_U * Kp + k];
     ASC_UNROLL
@@ -240,7 +252,8 @@ ASC_PASS Part hs_trial_chunk(const ldbl *dp, const ldbl *sc, int K, int Kp, int 
       ASC_UNROLL
       for (int i = 0; i < 7; i++) {
         z[i] += alpha * stp[(O_Z + i) * Kp + k];
-        zp[i] += k > 0 ? alpha * stp[(O_Z + i) * Kp + k - 1] : 0.0;
+        const double dpv = stp[(O_Z + i) * Kp + km];
+        zp[i] += k > 0 ? alpha * dpv : 0.0;
         l[i] += alpha * stp[(O_L + i) * Kp + k];
       }
       u += alpha * stp[O_U * Kp + k];
@@ -260,8 +273,10 @@ ASC_PASS Part hs_trial_chunk(const ldbl *dp, const ldbl *sc, int K, int Kp, int 
       ASC_UNROLL
       for (int b = 0; b < 6; b++) in[(O_ZB + b) * Kp + k] = zb[b];
     }
+    HPROF(0);
     HsPts pt;
     hs_points<0>(d, zp, z, u, t.dt, 0.0, 0.0, pt);
+    HPROF(1);
     double c[7], Jth[7];
     hs_defect(pt, zp, z, t.dt, t.hT, c, Jth);
     ASC_UNROLL
@@ -271,10 +286,12 @@ ASC_PASS Part hs_trial_chunk(const ldbl *dp, const ldbl *sc, int K, int Kp, int 
       P.rth += Jth[i] * l[i];
       P.l1 += fabs(l[i]);
     }
+    HPROF(2);
     HsDual q;
     hs_dual(pt, l, t.dt, q);
     ASC_UNROLL
     for (int i = 0; i < 7; i++) { ga[i] = q.ga[i]; r[i] = q.gb[i]; }
+    HPROF(3);
     r[IA] += zb[1] - zb[0];
     r[IM] += zb[3] - zb[2];
     if (k == K - 1) {
@@ -303,6 +320,7 @@ ASC_PASS Part hs_trial_chunk(const ldbl *dp, const ldbl *sc, int K, int Kp, int 
     const double ruv = -be * l[IW] - zb[4] + zb[5];
     P.rd = fmax(P.rd, fabs(ruv));
   }
+  HPROF(4);
   double gn[7];
   ASC_UNROLL
   for (int i = 0; i < 7; i++) gn[i] = __shfl_down(ga[i], 1);
@@ -319,6 +337,7 @@ ASC_PASS Part hs_trial_chunk(const ldbl *dp, const ldbl *sc, int K, int Kp, int 
     for (int i = 0; i < 7; i++) carry[C_TG + i] = ga[i];
   }
   wsync();
+  HPROF(5);
   return P;
 }
 
@@ -344,7 +363,9 @@ ASC_PASS double hs_eval_factor(const ldbl *dp, const gdbl *it, ldbl *stage, ldbl
     double zp[7], l[7];
     ASC_UNROLL
     for (int i = 0; i < 7; i++) {
-      z[i] = it[(O_Z + i) * Kp + k]; zp[i] = k > 0 ? it[(O_Z + i) * Kp + k - 1] : 0.0; l[i] = it[(O_L + i) * Kp + k];
+      z[i] = it[(O_Z + i) * Kp + k]; l[i] = it[(O_L + i) * Kp + k];
+      const double pv = it[(O_Z + i) * Kp + (k > 0 ? k - 1 : 0)];
+      zp[i] = k > 0 ? pv : 0.0;
     }
     u = it[O_U * Kp + k]; lw = l[IW];
     ASC_UNROLL
@@ -430,7 +451,11 @@ ASC_PASS double hs_eval_forward(const ldbl *dp, const gdbl *it, const gdbl *gain
   if (on) {
     double z[7], zp[7];
     ASC_UNROLL
-    for (int i = 0; i < 7; i++) { z[i] = it[(O_Z + i) * Kp + kn]; zp[i] = kn > 0 ? it[(O_Z + i) * Kp + kn - 1] : 0.0; }
+    for (int i = 0; i < 7; i++) {
+      z[i] = it[(O_Z + i) * Kp + kn];
+      const double pv = it[(O_Z + i) * Kp + (kn > 0 ? kn - 1 : 0)];
+      zp[i] = kn > 0 ? pv : 0.0;
+    }
     const double u_ = it[O_U * Kp + kn];
     ASC_UNROLL
     for (int i = 0; i < 7; i++) ka[i] = gains[(size_t)i * Kp + kn];
@@ -505,8 +530,10 @@ ASC_PASS double hs_eval_adjoint(const ldbl *dp, const ldbl *sc, const gdbl *it, 
     double zp[7], l[7], dzp[7];
     ASC_UNROLL
     for (int i = 0; i < 7; i++) {
-      z[i] = it[(O_Z + i) * Kp + kn]; zp[i] = kn > 0 ? it[(O_Z + i) * Kp + kn - 1] : 0.0; l[i] = it[(O_L + i) * Kp + kn];
-      dz[i] = stp[(O_Z + i) * Kp + kn]; dzp[i] = kn > 0 ? stp[(O_Z + i) * Kp + kn - 1] : 0.0;
+      const int km = kn > 0 ? kn - 1 : 0;
+      z[i] = it[(O_Z + i) * Kp + kn]; l[i] = it[(O_L + i) * Kp + kn]; dz[i] = stp[(O_Z + i) * Kp + kn];
+      const double pv = it[(O_Z + i) * Kp + km], dpv = stp[(O_Z + i) * Kp + km];
+      zp[i] = kn > 0 ? pv : 0.0; dzp[i] = kn > 0 ? dpv : 0.0;
     }
     const double u = it[O_U * Kp + kn];
     ASC_UNROLL
@@ -1241,6 +1268,9 @@ __global__ __launch_bounds__(WAVE) void h_solve(const ascent_params *params, lon
   }
   wsync();
   PROF_END;
+#ifdef PERSIST_PROFILE
+  if (blockIdx.x == 0 && threadIdx.x == 0) { printf("[hs trial] loads %llu points %llu defect %llu dual %llu rest %llu tail %llu\n", g_hsprof[0], g_hsprof[1], g_hsprof[2], g_hsprof[3], g_hsprof[4], g_hsprof[5]); for (int i = 0; i < 8; i++) g_hsprof[i] = 0; }
+#endif
   if (live)
     for (int r = role; r < NSCAL; r += 16) gsc[r] = sc[r];
 }
