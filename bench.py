@@ -416,11 +416,11 @@ def main():
                                              "converged": int((rh.status == 0).sum()), "of": len(Sh), "path": A.default_path(len(Sh), NT, scheme=2),
                                              "iterations_min_mean_max": [int(rh.iters.min()), float(rh.iters.mean()), int(rh.iters.max())],
                                              "roofline": roofline_of(Sh, NT, rh, msh, "hs4096", scheme=2, max_iter=500),
-                                             "what": "the config-3 sweep with Hermite-Simpson (scheme 2; dense-block path, host-steered rounds), DCOST not applied"}
+                                             "what": "the config-3 sweep with Hermite-Simpson (scheme 2; persistent kernel h_solve of csrc/ascent_hs.hip: structured step Jacobians, one launch per grid level), DCOST not applied"}
             r5, ms5 = timed(lambda: A.solve_batch(A.AscentParams(), 2000, tol=args.tol, scheme=2, terminal="ellipse", max_iter=500))
             o5 = r5.orbit()
             oc["config5_single_nlp"] = {"ms_per_solve": ms5, "converged": int((r5.status == 0).sum()), "iterations": int(r5.iters[0]),
-                                        "final_time_s": float(r5.final_time()[0]), "path": A.default_path(1, 2000, scheme=2),
+                                        "final_time_s": float(r5.final_time()[0]), "path": A.default_path(1, 2000, scheme=2, terminal="ellipse"),
                                         "orbit_periapsis_apoapsis_alt_m": [float(o5["periapsis_alt"][0]), float(o5["apoapsis_alt"][0])],
                                         "roofline": roofline_of(A.AscentParams().as_row()[None], 2000, r5, ms5, "config5_one", scheme=2, terminal="ellipse", max_iter=500),
                                         "what": "N=2000 Hermite-Simpson, terminal condition of the (r_peri, r_apo) ellipse (terminal 1), Kepler coast on the device; angular-acceleration bound active"}
@@ -429,14 +429,22 @@ def main():
             oc["config5_single_nlp_burnout_anywhere"] = {"ms_per_solve": ms5f, "converged": int((r5f.status == 0).sum()), "iterations": int(r5f.iters[0]),
                                                          "final_time_s": float(r5f.final_time()[0]), "burn_saved_vs_terminal1_ms": float((r5.final_time()[0] - r5f.final_time()[0]) * 1e3),
                                                          "orbit_periapsis_apoapsis_alt_m": [float(o5f["periapsis_alt"][0]), float(o5f["apoapsis_alt"][0])],
-                                                         "what": "the same grid with terminal 2: burnout anywhere on the ellipse (angular momentum and energy), the burn--coast problem with the coast arc eliminated exactly; Riccati form of the dense path (one wavefront)"}
+                                                         "path": A.default_path(1, 2000, scheme=2, terminal="ellipse_free"),
+                                                         "roofline": roofline_of(A.AscentParams().as_row()[None], 2000, r5f, ms5f, None, scheme=2, terminal="ellipse_free", max_iter=500),
+                                                         "what": "the same grid with terminal 2: burnout anywhere on the ellipse (angular momentum and energy), the burn--coast problem with the coast arc eliminated exactly; persistent Hermite-Simpson kernel, one NLP per wavefront"}
             S5 = A.sweep_isp_drymass(16, 16)
             r5b, ms5b = timed(lambda: A.solve_batch(S5, 2000, tol=args.tol, scheme=2, terminal="ellipse", max_iter=500, want_traj=False), n=2)
             oc["config5_batch256"] = {"value": float((r5b.status == 0).sum()) / (ms5b * 1e-3), "unit": "NLPs/s", "ms_per_solve": ms5b,
                                       "converged": int((r5b.status == 0).sum()), "of": 256, "path": A.default_path(256, 2000, scheme=2),
                                       "iterations_min_mean_max": [int(r5b.iters.min()), float(r5b.iters.mean()), int(r5b.iters.max())],
                                       "roofline": roofline_of(S5, 2000, r5b, ms5b, "config5", scheme=2, terminal="ellipse", max_iter=500),
-                                      "what": "256 NLPs (16 x 16 Isp x dry-mass sweep) at N=2000 Hermite-Simpson, terminal 1: config 5 as a batch"}
+                                      "what": "256 NLPs (16 x 16 Isp x dry-mass sweep) at N=2000 Hermite-Simpson, terminal 1: config 5 as a batch (persistent Hermite-Simpson kernel, one NLP per wavefront)"}
+            r5c, ms5c = timed(lambda: A.solve_batch(S5, 2000, tol=args.tol, scheme=2, terminal="ellipse_free", max_iter=500, want_traj=False), n=2)
+            oc["config5_batch256_burnout_anywhere"] = {"value": float((r5c.status == 0).sum()) / (ms5c * 1e-3), "unit": "NLPs/s", "ms_per_solve": ms5c,
+                                                       "converged": int((r5c.status == 0).sum()), "of": 256, "path": A.default_path(256, 2000, scheme=2, terminal="ellipse_free"),
+                                                       "iterations_min_mean_max": [int(r5c.iters.min()), float(r5c.iters.mean()), int(r5c.iters.max())],
+                                                       "roofline": roofline_of(S5, 2000, r5c, ms5c, None, scheme=2, terminal="ellipse_free", max_iter=500),
+                                                       "what": "the same batch with terminal 2"}
             line["other_configs"] = oc
         if world == 1 and not args.no_cpu_baseline:
             cb, idx, res = cpu_baseline(P, NT, args.tol, min(args.cpu_sample, B), move_penalty=mp)

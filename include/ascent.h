@@ -51,7 +51,8 @@ typedef struct ascent_opts {
   int32_t scheme;      /* 0 = NODES=2 two-point collocation = backward Euler (:25);
                           1 = trapezoid, control held over the step (not a reference scheme);
                           2 = Hermite-Simpson (compressed form, control held over the step; the method
-                              source the reference's report cites, PDF p3/p25) -- dense-block solver path */
+                              source the reference's report cites, PDF p3/p25) -- a persistent kernel of its
+                              own (h_solve); with move_penalty = 1 the dense-block solver path             */
   int32_t max_iter;    /* :28  interior-point iteration cap                              */
   int32_t warm_start;  /* 0 = built-in cold-start guess, 1 = primal part of `guess`,
                           2 = full primal-dual `guess` (multipliers kept)                */
@@ -79,8 +80,9 @@ typedef struct ascent_opts {
                                arc eliminated exactly (two-body motion): two conditions, angular momentum >= and specific energy
                                <= those of the ellipse (an orbit nested in the target annulus; both active at the optimum), no
                                r.v = 0; ascent_coast_batch continues from whatever true anomaly the burn ends at.
-                               Dense-block path (any scheme, formulation 0)                                   */
-  int32_t solver_path;  /* 0 = automatic (hand-tuned sparse kernels for schemes 0/1, dense-block path for scheme 2);
+                               Persistent kernels (every scheme) and dense-block path, formulation 0           */
+  int32_t solver_path;  /* 0 = automatic (the persistent kernels: p_solve for schemes 0/1, h_solve for scheme 2; a handful of NLPs on a long
+                               grid and scheme 2 with the move penalty: the dense-block path; ascent_default_path tells);
                            ASCENT_PATH_DENSE = the dense-block path for any scheme (formulation 0 only)       */
   int32_t move_penalty; /* 0 = ascent_params.dcost is ignored (a sweep's parameter sets may carry none);
                            1 = :99 angledoubledot.DCOST applied -- the model the reference declares: the objective is
@@ -136,10 +138,11 @@ const char *ascent_strerror(int code);
  * traj_out [10*n_nodes][batch], tf_out/status_out/iters_out [batch]; sol_blob_out_or_null
  * [21K+10][batch] receives the full primal-dual solution (usable as a warm start).
  * stream: hipStream_t or NULL.  With host pointers the call returns after the results are in the
- * caller's buffers.  With ptr_is_device != 0 and a stream, the persistent kernel (schemes 0 and 1, both
- * formulations, with or without the move penalty, every terminal mode: the default at every batch size; ascent_default_path) is
- * only enqueued -- a handful of launches per grid level, no host involvement (with the NULL stream the call waits for the solve); the split pipeline (ASCENT_PIPELINE=split) and the dense-block path (scheme 2, a few NLPs
- * on long grids) synchronise the stream once per burst of interior-point rounds, because the host steers the
+ * caller's buffers.  With ptr_is_device != 0 and a stream, the persistent kernels (schemes 0 and 1, both
+ * formulations, with or without the move penalty; scheme 2 without it; every terminal mode: the default at every batch size,
+ * ascent_default_path) are only enqueued -- a handful of launches per grid level, no host involvement (with the NULL stream the
+ * call waits for the solve); the split pipeline (ASCENT_PIPELINE=split) and the dense-block path (scheme 2 with the move
+ * penalty, a few NLPs on long grids) synchronise the stream once per burst of interior-point rounds, because the host steers the
  * rounds, and return with the last kernels enqueued.
  * Concurrency: host-side, calls on one device are serialised by a mutex.  Device-side, the library keeps a workspace per
  * caller stream (up to three non-default streams per device; the default stream, the parity surfaces and any further
@@ -178,15 +181,16 @@ int ascent_kkt_step(const ascent_params *p, int64_t batch, const ascent_opts *o,
  *   ASCENT_PATH_FUSED       k_eval_nodes / the passes of k_solve (scheme 0, formulation 0 only)
  *   ASCENT_PATH_SPLIT_LANE  q_trial_eval -> q_decide_factor -> q_forward -> q_local -> q_adjoint
  *   ASCENT_PATH_SPLIT_WIDE  q_trial_eval -> q_factor_wide -> q_forward_wide -> q_local -> q_adjoint_wide
- *   ASCENT_PATH_PERSIST     p_solve (the default of ascent_solve_batch): see the enum below
+ *   ASCENT_PATH_PERSIST     p_solve / h_solve (the default of ascent_solve_batch): see the enum below
  *   ASCENT_PATH_DENSE       d_eval -> d_newton (ascent_kkt_step_path; with move_penalty = 1 as well, like ASCENT_PATH_PERSIST)
  * The split paths take schemes 0/1 and formulations 0/1.  For scheme 1 (trapezoid) `defects` is the trapezoid
  * defect and the Hessian block of node k is weighted by -(h*T*tf/2)*(lambda_k + lambda_{k+1}). */
 enum ascent_path { ASCENT_PATH_AUTO = 0, ASCENT_PATH_FUSED = 1, ASCENT_PATH_SPLIT_LANE = 2, ASCENT_PATH_SPLIT_WIDE = 3,
                    ASCENT_PATH_DENSE = 4, /* d_eval -> d_newton, one wavefront per NLP on dense 8x8 blocks: schemes 0/1/2 */
-                   ASCENT_PATH_PERSIST = 5 /* one round of p_solve, the persistent kernel (schemes 0 / 1, formulation 1 with scheme 0):
-                                              ascent_kkt_step_path returns its Newton step; ascent_eval_nodes_path the node rows it
-                                              stages in LDS for the factorisation sweep, copied out before the sweep would read them */ };
+                   ASCENT_PATH_PERSIST = 5 /* one round of the persistent kernel -- p_solve (schemes 0 / 1, formulation 1 with scheme 0) or
+                                              h_solve (scheme 2, Hermite-Simpson, without the move penalty): ascent_kkt_step_path returns its
+                                              Newton step; ascent_eval_nodes_path (schemes 0 / 1) the node rows it stages in LDS for the
+                                              factorisation sweep, copied out before the sweep would read them */ };
 /* Which kernels ascent_solve_batch runs for a batch of this size with these options (and the environment overrides):
  * an ascent_path value, never ASCENT_PATH_AUTO.  No device work. */
 int ascent_default_path(int64_t batch, const ascent_opts *o);
