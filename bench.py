@@ -443,7 +443,7 @@ def main():
             oc["config5_batch256_burnout_anywhere"] = {"value": float((r5c.status == 0).sum()) / (ms5c * 1e-3), "unit": "NLPs/s", "ms_per_solve": ms5c,
                                                        "converged": int((r5c.status == 0).sum()), "of": 256, "path": A.default_path(256, 2000, scheme=2, terminal="ellipse_free"),
                                                        "iterations_min_mean_max": [int(r5c.iters.min()), float(r5c.iters.mean()), int(r5c.iters.max())],
-                                                       "roofline": roofline_of(S5, 2000, r5c, ms5c, None, scheme=2, terminal="ellipse_free", max_iter=500),
+                                                       "roofline": roofline_of(S5, 2000, r5c, ms5c, "config5_free", scheme=2, terminal="ellipse_free", max_iter=500),
                                                        "what": "the same batch with terminal 2"}
             line["other_configs"] = oc
         if world == 1 and not args.no_cpu_baseline:

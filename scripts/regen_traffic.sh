@@ -5,7 +5,7 @@
 set -e
 R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-WL=${@:-config3 config3_nodcost config4 hs4096 config5 config5_one}
+WL=${@:-config3 config3_nodcost config4 hs4096 config5 config5_free config5_one}
 for W in $WL; do
   export PROF_WORKLOAD=$W
   rm -rf $R/gpurun_out/tr_${W}_stats $R/gpurun_out/tr_${W}_fetch $R/gpurun_out/tr_${W}_write

@@ -9,7 +9,7 @@ t0 = time.time()
 for rep in range(12):
     for (B, nt, kw) in ((1, 200, {}), (100, 60, {}), (4096, 200, {}), (20000, 200, {}), (300, 200, dict(scheme=1)),
                         (64, 200, dict(formulation=1, params=A.AscentParams(r_peri=53108.4, r_apo=53108.4, mass_scalar=2576.0))),
-                        (16, 200, dict(scheme=2)), (100, 120, dict(move_penalty=True, params=A.AscentParams(dcost=1e-5)))):
+                        (16, 200, dict(scheme=2)), (2000, 150, dict(scheme=2, terminal="ellipse")), (30, 500, dict(scheme=2, terminal="ellipse_free")), (100, 120, dict(move_penalty=True, params=A.AscentParams(dcost=1e-5)))):
         base = kw.pop("params", None) if "params" in kw else None
         kw2 = {k: v for k, v in kw.items()}
         n = int(round(B ** 0.5))

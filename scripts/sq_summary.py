@@ -1,4 +1,4 @@
-"""Developer tool: summary of the SQ counters scripts/sq_counters.sh collected: per p_solve dispatch of the LARGEST grid level
+"""Developer tool: summary of the SQ counters scripts/sq_counters.sh collected: per p_solve / h_solve dispatch of the LARGEST grid level
 (the one with the most SQ_WAVE_CYCLES), averaged over the solves -- instruction mix, issue / wait / stall shares per wavefront.
 (SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles: x4 for shader cycles, MI355X_MICROARCH.md)"""
 import csv, glob, os, sys
@@ -7,7 +7,7 @@ for d in sys.argv[1:3]:
     f = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)[0]
     per = {}
     for r in csv.DictReader(open(f)):
-        if "p_solve" not in r["Kernel_Name"]:
+        if "p_solve" not in r["Kernel_Name"] and "h_solve" not in r["Kernel_Name"]:      # (h_solve: the Hermite-Simpson kernel)
             continue
         per.setdefault(r["Dispatch_Id"], {})[r["Counter_Name"]] = float(r["Counter_Value"])
     # the fine-level dispatches: those with the largest value of the pass's first cycle-like counter
@@ -16,7 +16,7 @@ for d in sys.argv[1:3]:
     fine = [v for v in per.values() if v[key] > 0.6 * big]
     for k in fine[0]:
         tot[k] = sum(v[k] for v in fine) / len(fine)
-    print(f"{d}: {len(per)} p_solve dispatches, {len(fine)} of the finest grid level")
+    print(f"{d}: {len(per)} p_solve / h_solve dispatches, {len(fine)} of the finest grid level")
 for k in sorted(tot):
     print(f"  {k:22s} {tot[k]:.4g}")
 w = tot["SQ_WAVES"]

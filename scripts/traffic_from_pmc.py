@@ -19,7 +19,7 @@ from bench import source_sha16  # noqa: E402  (the stamp bench.py checks before 
 
 
 def short(name):
-    m = re.search(r"\b(q_\w+|k_\w+|p_\w+|d_\w+|bt_\w+|pc_\w+)", name)
+    m = re.search(r"\b(q_\w+|k_\w+|p_\w+|h_solve|d_\w+|bt_\w+|pc_\w+)", name)
     return m.group(1) if m else name[:24]
 
 
@@ -38,7 +38,7 @@ def counters(d, counter):
 
 
 def fetch_factor(kernel):
-    return 1.0 if kernel.startswith("p_") else 2.0
+    return 1.0 if kernel.startswith(("p_", "h_")) else 2.0      # (h_solve: the layout and the 8-byte node-contiguous accesses of p_solve)
 
 
 def counters_per_kernel(d, counter):
@@ -60,7 +60,7 @@ stats = {}
 f = glob.glob(os.path.join(stats_dir, "**", "*kernel_stats.csv"), recursive=True)[0]
 for r in csv.DictReader(open(f)):
     k = short(r["Name"])
-    if not k.startswith(("q_", "k_", "p_", "d_", "bt_", "pc_")):
+    if not k.startswith(("q_", "k_", "p_", "h_", "d_", "bt_", "pc_")):
         continue
     stats[k] = {"calls_per_solve": int(r["Calls"]) / n_solves, "avg_us": float(r["AverageNs"]) / 1e3,
                 "ms_per_solve": float(r["TotalDurationNs"]) / 1e6 / n_solves, "percent": float(r["Percentage"])}
