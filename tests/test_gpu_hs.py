@@ -120,3 +120,22 @@ def test_hs_persistent_config5_batch():
     assert np.all(r2.tf <= r1.tf + 1e-9)
     by = _fixtures()
     assert abs(r1.tf[0] - by[(2000, 2, "periapsis")]["tf"]) < 1e-7 and abs(r2.tf[0] - by[(2000, 2, "ellipse")]["tf"]) < 1e-7
+
+
+def test_hs_persistent_unusual_grid_sizes(monkeypatch):
+    """Grids from three nodes up, ending one short of / exactly on / one past the chunk boundaries of both kernel forms (12 and 48 nodes),
+    single-grid and nested: the persistent Hermite-Simpson kernel and the dense-block path arrive at the same t_f in the same number of
+    iterations (one more or less where the KKT error passes the tolerance within rounding of it)."""
+    S = np.vstack([A.AscentParams().as_row()[None], A.sweep_isp_drymass(2, 2)])[:3]
+    for nt in (3, 4, 5, 12, 13, 14, 25, 37, 48, 49, 50, 97, 98, 145):
+        res = {}
+        for path in ("persist", "dense"):
+            monkeypatch.setenv("ASCENT_PIPELINE", path)
+            monkeypatch.setenv("ASCENT_DENSE_NEWTON", "riccati")
+            res[path] = A.solve_batch(S, nt, tol=1e-9, scheme=2, max_iter=500)
+        p, d = res["persist"], res["dense"]
+        assert np.array_equal(p.status, d.status), (nt, p.status, d.status)
+        ok = p.status == 0
+        assert ok.sum() >= 2 or nt < 5, (nt, p.status)         # (three- and four-node grids of the off-nominal problems need not have a solution)
+        assert np.abs(p.iters[ok].astype(int) - d.iters[ok]).max(initial=0) <= 1, (nt, p.iters, d.iters)
+        assert np.abs(p.tf[ok] - d.tf[ok]).max(initial=0.0) <= 1e-9, nt
