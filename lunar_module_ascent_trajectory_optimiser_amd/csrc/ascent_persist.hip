@@ -1458,7 +1458,8 @@ namespace ascent {
 static PGeo geo_of(int K, int form = 0, int mp = 0, int term = 0, int wide = 0, int scheme = 0) {
   PGeo g;
   const int ch = scheme == 2 ? hs_chunk_nodes(wide) : wide ? 64 : CH;
-  g.K = K; g.nch = (K + ch - 1) / ch; g.Kp = g.nch * ch; g.form = form; g.mp = mp ? 1 : 0; g.term = term == 2 ? 2 : 0; g.wide = wide ? 1 : 0;
+  g.K = K; g.nch = (K + ch - 1) / ch; g.Kp = (g.nch * ch + 15) / 16 * 16;      // (rows of an NLP start on 128-byte lines: see PGeo::nlp_doubles)
+  g.form = form; g.mp = mp ? 1 : 0; g.term = term == 2 ? 2 : 0; g.wide = wide ? 1 : 0;
   return g;
 }
 // Batches that cannot give every SIMD a wavefront of four NLPs (MI355X: 256 CUs x 4 SIMDs) run one NLP per wavefront; the

@@ -45,6 +45,8 @@ enum {
   X_D = X_S + 10,            // 10 step scalars
   NSCAL = X_D + 10
 };
+constexpr int NSCAL_PAD = 64;
+static_assert(NSCAL <= NSCAL_PAD, "scalar record");
 enum { ST_TRIAL = 0, ST_FACTOR = 1, ST_FACTORED = 2, ST_DONE = 3 };
 
 struct PGeo {
@@ -52,7 +54,9 @@ struct PGeo {
   __host__ __device__ int nit() const { return mp ? Lay<1>::NIT : Lay<0>::NIT; }
   __host__ __device__ int r_st() const { return 2 * nit(); }
   __host__ __device__ int nrows() const { return mp ? Lay<1>::NROWS : Lay<0>::NROWS; }
-  __host__ __device__ size_t nlp_doubles() const { return (size_t)nrows() * Kp + NSCAL; }
+  // (the scalar record padded to 64 doubles: with Kp a multiple of 16 every NLP then starts on a 128-byte line, and so does every row of it --
+  //  a chunk row of an NLP is ONE line instead of straddling two)
+  __host__ __device__ size_t nlp_doubles() const { return (size_t)nrows() * Kp + NSCAL_PAD; }
 };
 
 template <int SRC>
