@@ -1462,12 +1462,12 @@ static PGeo geo_of(int K, int form = 0, int mp = 0, int term = 0, int wide = 0, 
   g.form = form; g.mp = mp ? 1 : 0; g.term = term == 2 ? 2 : 0; g.wide = wide ? 1 : 0;
   return g;
 }
-// Batches that cannot give every SIMD a wavefront of four NLPs (MI355X: 256 CUs x 4 SIMDs) run one NLP per wavefront; the
-// trapezoid with the move penalty and terminal 2 keep the four-NLP form (fewer instantiations of a large kernel).
+// Batches that cannot give every SIMD a wavefront of four NLPs (MI355X: 256 CUs x 4 SIMDs) run one NLP per wavefront
+// (every variant of the kernel has both forms).
 static int use_wide(long batch, int scheme, int form, int mp, int term) {
-  const bool have = scheme == 2 ? true : term == 0 && !(scheme == 1 && mp);
-  if (const char *e = getenv("ASCENT_PERSIST_WIDE")) return e[0] == '1' && have;
-  return batch <= 1024 && have;
+  (void)scheme; (void)form; (void)mp; (void)term;
+  if (const char *e = getenv("ASCENT_PERSIST_WIDE")) return e[0] == '1';
+  return batch <= 1024;
 }
 
 // One grid level's workspace, rounded up to a multiple of 256 bytes: the two regions of the nested iteration are laid out
@@ -1504,7 +1504,15 @@ static void launch_solve(int scheme, int form, int mp, long batch, hipStream_t s
   }
   if (g.wide) {      // one NLP per wavefront
     const dim3 gw((unsigned)batch), bw(WAVE);
-    if (mp && form == 1) hipLaunchKernelGGL((p_solve<0, 1, 1, 0, 1>), gw, bw, 0, stream, dp, batch, g, w, max_iter, tol);
+    if (g.term == 2) {      // burnout anywhere on the ellipse (formulation 0)
+      if (mp && scheme == 1) hipLaunchKernelGGL((p_solve<1, 0, 1, 2, 1>), gw, bw, 0, stream, dp, batch, g, w, max_iter, tol);
+      else if (mp) hipLaunchKernelGGL((p_solve<0, 0, 1, 2, 1>), gw, bw, 0, stream, dp, batch, g, w, max_iter, tol);
+      else if (scheme == 1) hipLaunchKernelGGL((p_solve<1, 0, 0, 2, 1>), gw, bw, 0, stream, dp, batch, g, w, max_iter, tol);
+      else hipLaunchKernelGGL((p_solve<0, 0, 0, 2, 1>), gw, bw, 0, stream, dp, batch, g, w, max_iter, tol);
+      return;
+    }
+    if (mp && scheme == 1) hipLaunchKernelGGL((p_solve<1, 0, 1, 0, 1>), gw, bw, 0, stream, dp, batch, g, w, max_iter, tol);
+    else if (mp && form == 1) hipLaunchKernelGGL((p_solve<0, 1, 1, 0, 1>), gw, bw, 0, stream, dp, batch, g, w, max_iter, tol);
     else if (form == 1) hipLaunchKernelGGL((p_solve<0, 1, 0, 0, 1>), gw, bw, 0, stream, dp, batch, g, w, max_iter, tol);
     else if (mp) hipLaunchKernelGGL((p_solve<0, 0, 1, 0, 1>), gw, bw, 0, stream, dp, batch, g, w, max_iter, tol);
     else if (scheme == 1) hipLaunchKernelGGL((p_solve<1, 0, 0, 0, 1>), gw, bw, 0, stream, dp, batch, g, w, max_iter, tol);

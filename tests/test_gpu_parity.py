@@ -814,3 +814,30 @@ def test_persistent_kernel_v1_formulation_matches_split_pipeline_and_oracle(cora
     assert A.default_path(1, NT, formulation=1) == "persist"
     v = A.solve_batch(base, NT, tol=1e-9, formulation="v1", max_iter=500)
     assert v.status[0] == 0 and abs(v.final_time()[0] - 435.29773) < 2e-3        # PDF p30: 435.29773 s (here 435.29896)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("scheme,mp,terminal,formulation", [(0, False, 0, 0), (1, False, 0, 0), (0, True, 0, 0), (1, True, 0, 0), (0, False, 0, 1),
+                                                            (0, True, 0, 1), (0, False, 2, 0), (1, False, 2, 0), (0, True, 2, 0), (1, True, 2, 0)])
+def test_one_nlp_per_wavefront_equals_four_per_wavefront(monkeypatch, scheme, mp, terminal, formulation):
+    """Every variant of the persistent kernel (scheme x move penalty x terminal condition x formulation) exists in both forms --
+    four NLPs per wavefront with 16-node chunks, and one NLP per wavefront with 64-node chunks (the default for batches <= 1024:
+    ASCENT_PERSIST_WIDE overrides).  Same arithmetic per node and per sweep step (sums over the nodes run 16 or 64 at a time), so: identical iteration
+    counts and t_f to 1e-12 -- with terminal 2 (two nearly dependent conditions, iteration counts that depend on the last bit) convergence and t_f to 5e-9 -- on a ragged batch and on grids that end inside a chunk of either form."""
+    S = A.sweep_isp_drymass(3, 3)[:7]
+    S[:, 15] = 1e-5
+    for nt in (60, 131):
+        out = {}
+        for wide in ("0", "1"):
+            monkeypatch.setenv("ASCENT_PERSIST_WIDE", wide)
+            assert A.default_path(len(S), nt, scheme=scheme, move_penalty=mp, terminal=terminal, formulation=formulation) == "persist"
+            out[wide] = A.solve_batch(S, nt, tol=1e-9, scheme=scheme, move_penalty=mp, terminal=terminal, formulation=formulation, max_iter=500)
+        monkeypatch.delenv("ASCENT_PERSIST_WIDE")
+        assert np.all(out["0"].status == 0) and np.all(out["1"].status == 0), (nt, out["0"].status, out["1"].status)
+        if terminal == 2:      # (its two nearly dependent conditions: 50-60 iterations, the convergence test now and then a knife edge)
+            assert np.abs(out["0"].tf - out["1"].tf).max() <= 5e-9      # (iteration counts: 29-94, and tens apart between the forms on single problems)
+            continue          # (where on the ellipse the burn ends is a nearly flat direction of t_f: the states of two KKT points at tol 1e-9 differ by 1e-4)
+        else:
+            assert np.array_equal(out["0"].iters, out["1"].iters), (nt, out["0"].iters, out["1"].iters)
+            assert np.abs(out["0"].tf - out["1"].tf).max() <= 1e-12
+        assert np.abs(out["0"].traj[:8] - out["1"].traj[:8]).max() <= 1e-6      # (sums over the nodes run 16 / 64 at a time: the control at the junction of its arcs is only weakly determined, DESIGN.md section 3)
