@@ -445,6 +445,22 @@ def main():
                                                        "iterations_min_mean_max": [int(r5c.iters.min()), float(r5c.iters.mean()), int(r5c.iters.max())],
                                                        "roofline": roofline_of(S5, 2000, r5c, ms5c, "config5_free", scheme=2, terminal="ellipse_free", max_iter=500),
                                                        "what": "the same batch with terminal 2"}
+            if not args.no_cpu_baseline:
+                # BASELINE.json configs[1] beside ONE host core: the C restatement of the same algorithm on the same single problem
+                # (median of 5 solves, one thread; a stated baseline like cpu_baseline below, never the target)
+                from oracle import c_oracle
+                c_oracle.build()
+                def one_core(**kw):
+                    row = A.AscentParams(dcost=1e-5).as_row()[None]
+                    c_oracle.solve_batch(row, NT, 500, args.tol, **kw)
+                    ts = []
+                    for _ in range(5):
+                        t0 = time.perf_counter(); c_oracle.solve_batch(row, NT, 500, args.tol, **kw); ts.append(time.perf_counter() - t0)
+                    return float(np.median(ts)) * 1e3
+                for key, kw in (("config1_single_nlp", {}), ("config1_single_nlp_trapezoid", {"scheme": 1}), ("config1_single_nlp_with_dcost", {"move_penalty": True})):
+                    oc[key]["cpu_one_core_ms"] = one_core(**kw)
+                    oc[key]["cpu_one_core_what"] = "the plain-C restatement (oracle/) of the same algorithm, same problem, tolerance and cold start, one host thread"
+                c_oracle.set_scheme(0)
             line["other_configs"] = oc
         if world == 1 and not args.no_cpu_baseline:
             cb, idx, res = cpu_baseline(P, NT, args.tol, min(args.cpu_sample, B), move_penalty=mp)

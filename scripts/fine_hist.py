@@ -1,12 +1,15 @@
-"""Iterations per grid level of the config-3 sweep (default nested iteration): histograms, and how they sit in wavefronts of four."""
-import sys
+"""Iterations per grid level of the config-3 sweep (default nested iteration): histograms, and how they sit in wavefronts of four.
+MP=1: with the move penalty (the reference's DCOST = 1e-5)."""
+import os, sys
 sys.path.insert(0, ".")
 import numpy as np
 import lunar_module_ascent_trajectory_optimiser_amd as A
 S = A.sweep_isp_drymass()
-tot = A.solve_batch(S, 200, tol=1e-9, want_traj=False).iters.astype(int)
-upto60 = A.solve_batch(S, 60, tol=1e-3, want_traj=False).iters.astype(int)
-upto17 = A.solve_batch(S, 17, tol=1e-3, want_traj=False, coarse_nodes=-1).iters.astype(int)
+mp = os.environ.get("MP", "0") == "1"
+S[:, 15] = 1e-5
+tot = A.solve_batch(S, 200, tol=1e-9, want_traj=False, move_penalty=mp).iters.astype(int)
+upto60 = A.solve_batch(S, 60, tol=1e-3, want_traj=False, move_penalty=mp).iters.astype(int)
+upto17 = A.solve_batch(S, 17, tol=1e-3, want_traj=False, coarse_nodes=-1, move_penalty=mp).iters.astype(int)
 for name, it in (("17-node level", upto17), ("60-node level", upto60 - upto17), ("200-node level", tot - upto60)):
     w = it.reshape(-1, 4).max(axis=1)
     print(f"{name}: hist {np.bincount(it)[it.min():].tolist()} from {it.min()}; mean {it.mean():.2f} max {it.max()}; wavefront maxima: mean {w.mean():.2f} max {w.max()}")
