@@ -147,6 +147,9 @@ def test_persistent_workspace_regions_fit_the_allocation(lib):
                 total, used0, off1, used1 = out
                 assert nlev >= 2 and used0 > 0 and used1 > 0
                 assert used0 <= off1 and off1 % 256 == 0 and off1 + used1 <= total, (mp, nt, batch, list(out))
+                # every NLP's record is a whole number of 128-byte lines (its node rows are padded to 16 nodes, its scalar record to 64
+                # doubles): a 16-node row of any NLP is ONE cache line, not two
+                assert used0 % batch == 0 and (used0 // batch) % 128 == 0 and used1 % batch == 0 and (used1 // batch) % 128 == 0, (mp, nt, batch, list(out))
     o = _lib.AscentOptsC(n_nodes=200, scheme=0, max_iter=10, warm_start=0, tol=1e-8, mu_init=0.0, coarse_nodes=-1)
     assert lib.ascent_workspace_layout(7, C.byref(o), out) == 1 and out[1] <= out[0] and out[2] == 0
 
