@@ -417,6 +417,12 @@ def main():
                                              "iterations_min_mean_max": [int(rh.iters.min()), float(rh.iters.mean()), int(rh.iters.max())],
                                              "roofline": roofline_of(Sh, NT, rh, msh, "hs4096", scheme=2, max_iter=500),
                                              "what": "the config-3 sweep with Hermite-Simpson (scheme 2; persistent kernel h_solve of csrc/ascent_hs.hip: structured step Jacobians, one launch per grid level), DCOST not applied"}
+            rhd, mshd = timed(lambda: A.solve_batch(Sh, NT, tol=args.tol, scheme=2, max_iter=500, want_traj=False, move_penalty=True), n=2)
+            oc["config3_hermite_simpson_with_dcost"] = {"value": float((rhd.status == 0).sum()) / (mshd * 1e-3), "unit": "NLPs/s", "ms_per_solve": mshd,
+                                                        "converged": int((rhd.status == 0).sum()), "of": len(Sh),
+                                                        "path": A.default_path(len(Sh), NT, scheme=2, move_penalty=True),
+                                                        "iterations_min_mean_max": [int(rhd.iters.min()), float(rhd.iters.mean()), int(rhd.iters.max())],
+                                                        "what": "the same sweep with Hermite-Simpson AND the move penalty: the one combination the persistent kernels do not carry -- dense-block path (d_eval / d_newton, host-steered rounds), 8x slower than either alone"}
             r5, ms5 = timed(lambda: A.solve_batch(A.AscentParams(), 2000, tol=args.tol, scheme=2, terminal="ellipse", max_iter=500))
             o5 = r5.orbit()
             oc["config5_single_nlp"] = {"ms_per_solve": ms5, "converged": int((r5.status == 0).sum()), "iterations": int(r5.iters[0]),
