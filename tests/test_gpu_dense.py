@@ -421,3 +421,36 @@ def test_move_penalty_across_the_config4_box_and_on_long_grids():
         r1 = A.solve_batch(P, nt, tol=1e-9, scheme=scheme, terminal=term, max_iter=500, move_penalty=True)
         assert r0.status[0] == 0 and r1.status[0] == 0
         assert 1.0e-3 < (r1.tf[0] - r0.tf[0]) * 470.0 < 2.5e-3 and tv(r1) < 0.7 * tv(r0)
+
+
+@pytest.mark.gpu
+def test_pcr_newton_step_at_a_wrong_inertia_iterate(coracle, monkeypatch):
+    """What the cyclic-reduction variant guarantees where the Riccati forms refuse: at an iterate with strongly negative curvature
+    (flipped defect multipliers) the recursion reports the wrong inertia; parallel cyclic reduction exposes no pivots, so it either
+    refuses too (its curvature test along the step) or hands back a step -- and then that step must be the solution of the KKT system
+    as it stands (generic sparse LU of the full matrix, nothing stage-structured): a correct Newton step of an indefinite system,
+    whose acceptance is the line search's business.  Also with a regularisation large enough to restore the inertia: both forms and
+    the LU agree.  (include/ascent.h documents the weaker guarantee; the dispatch routes only a handful of NLPs on long grids here.)"""
+    from conftest import generic_lu_newton_step, params_of_row, random_interior_blob
+    nt = 40
+    Kk = nt - 1
+    S = A.sweep_isp_drymass(1, 1)
+    blob = random_interior_blob(nt, 2, S[0], coracle)
+    bad = blob.copy()
+    bad[8 * Kk:15 * Kk] *= -50.0
+    out = {}
+    for mode in ("riccati", "pcr"):
+        monkeypatch.setenv("ASCENT_DENSE_NEWTON", mode)
+        out[mode] = A.kkt_step(S, bad[:, None], 1e-6, 0.0, nt, path="dense")
+        out[mode + "_reg"] = A.kkt_step(S, bad[:, None], 1e-6, 1e4, nt, path="dense")
+    assert out["riccati"][1][0] == 1                                     # the exact inertia says no
+    lu = generic_lu_newton_step(params_of_row(S[0]), nt, bad, 1e-6, 0.0)
+    lu = lu[0] if isinstance(lu, tuple) else lu
+    if out["pcr"][1][0] == 0:
+        assert np.abs(out["pcr"][0][:, 0] - lu).max() <= 1e-7 * max(1.0, np.abs(lu).max())
+    # a regularisation that makes the (z, u) block positive definite again: everybody solves the same system
+    lur = generic_lu_newton_step(params_of_row(S[0]), nt, bad, 1e-6, 1e4)
+    lur = lur[0] if isinstance(lur, tuple) else lur
+    for mode in ("riccati_reg", "pcr_reg"):
+        assert out[mode][1][0] == 0, mode
+        assert np.abs(out[mode][0][:, 0] - lur).max() <= 1e-7 * max(1.0, np.abs(lur).max()), mode
